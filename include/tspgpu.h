@@ -1,0 +1,158 @@
+/*
+ * include/tspgpu.h -- C ABI of the MI355X (gfx950) 2-opt local-search engine.
+ *
+ * This is the drop-in boundary for the heuristic path of
+ * enricobolzonello/TravellingSalesmanOptimization.  The reference has no
+ * plugin/FFI layer: its boundary is a set of plain C functions over two
+ * process-wide globals (src/tsp.h:235-236).  Each entry point below names the
+ * reference function (file:line under the reference checkout) whose work it
+ * takes over; the host-side C layer in travellingsalesmanoptimization_amd/host/
+ * keeps the reference's own signatures on top of these.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no global state; one opaque context per
+ *     caller thread (contexts are independent, so the CPLEX callback threads
+ *     of src/algorithms/cplex_model.c:1176-1258 can each own one).
+ *   - return value: the reference's ERROR_CODE numbering
+ *     (src/utils/errors.h:33-51): 0 T_OK, 3 INVALID_ARGUMENT,
+ *     4 DEADLINE_EXCEEDED (a success, src/utils/errors.c:31-37),
+ *     8 RESOURCE_EXHAUSTED, 9 FAILED_PRECONDITION, 12 UNIMPLEMENTED,
+ *     13 INTERNAL (HIP runtime failure), 14 UNAVAILABLE (no device).
+ *   - tours are SUCCESSOR arrays, path[i] = node visited after node i
+ *     (src/algorithms/refinment.c:51-52), exactly as tsp_solution.path.
+ *   - cost matrices are row-major n x n doubles, as tsp_inst.costs.
+ *   - there is NO CPU fallback: without a HIP device every call fails.
+ */
+#ifndef TSPGPU_H
+#define TSPGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tspgpu_ctx tspgpu_ctx;
+
+/* edge-weight kinds for tspgpu_set_points.  EUC_2D reproduces src/tsp.c:629
+ * bit for bit (float sqrt of a double sum).  ATT / CEIL_2D are TSPLIB 95
+ * definitions in double; the reference rejects them (src/tsp.c:576-584). */
+enum { TSPGPU_EUC_2D = 0, TSPGPU_ATT = 1, TSPGPU_CEIL_2D = 2 };
+
+/* storage of the device-resident cost matrix.  AUTO keeps an exact int32 copy
+ * when every entry is an integer in [-1, 2^28) (true for every EUC_2D / ATT /
+ * CEIL_2D matrix), else doubles. */
+enum { TSPGPU_ELEM_AUTO = 0, TSPGPU_ELEM_F64 = 1, TSPGPU_ELEM_I32 = 2 };
+
+/* tunables (tspgpu_set_option) */
+enum {
+    TSPGPU_OPT_ELEM = 1,        /* TSPGPU_ELEM_*; takes effect at the next build/set_costs */
+    TSPGPU_OPT_KERNEL = 2,      /* 0 auto, 1 force "simple" sweep, 2 force "pipelined" sweep */
+    TSPGPU_OPT_BATCH = 3,       /* sweeps enqueued between host polls (default 32) */
+    TSPGPU_OPT_WGS_PER_TOUR = 4,/* workgroups per tour in the sweep (0 = auto) */
+    TSPGPU_OPT_HISTORY = 5,     /* record (a,b,delta) of the first N sweeps of slot 0 */
+    TSPGPU_OPT_GRAPH = 6,       /* 1 = replay sweep batches as a hipGraph (default 1) */
+    TSPGPU_OPT_TIMING = 7,      /* 1 = bracket every sweep kernel with HIP events */
+    TSPGPU_OPT_BLOCK = 8,       /* threads per sweep workgroup (0 = auto) */
+    TSPGPU_OPT_MAX_TOURS = 9    /* tours kept in flight by the multi-start driver */
+};
+
+int  tspgpu_device_count(void);
+int  tspgpu_create(int device, tspgpu_ctx **out);
+void tspgpu_destroy(tspgpu_ctx *ctx);
+const char *tspgpu_last_error(const tspgpu_ctx *ctx);
+int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
+/* info: 0 n, 1 row stride, 2 element kind in use, 3 sweep kernel in use,
+ * 4 workgroups per tour, 5 LDS bytes per workgroup, 6 threads per workgroup,
+ * 7 matrix is symmetric, 8 compute units */
+long tspgpu_info(const tspgpu_ctx *ctx, int what);
+
+/* ---- instance / cost matrix ------------------------------------------- */
+
+/* Upload n points ({x,y} doubles = the reference's `point`, src/utils/utils.h:37-40). */
+int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_type);
+
+/* Replaces tsp_compute_costs (src/tsp.c:608-636): builds the n x n matrix on
+ * the device from the uploaded points.  host_out may be NULL; otherwise it
+ * receives the row-major n x n doubles (what tsp_inst.costs holds). */
+int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out);
+
+/* Caller-supplied matrix, the h_Greedy_2opt_mod_costs case
+ * (src/algorithms/heuristics.c:118-149): row-major n x n doubles. */
+int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n);
+
+/* Read the device matrix back (row-major n x n doubles). */
+int tspgpu_get_costs(tspgpu_ctx *ctx, double *host_out);
+
+/* ---- single-tour entry points (host arrays in/out) --------------------- */
+
+/* h_greedyutil (src/algorithms/heuristics.c:216-288): nearest-neighbour tour
+ * from `start`, ties to the lowest index.  14 if start is out of range. */
+int tspgpu_nn_tour(tspgpu_ctx *ctx, int start, int *path, double *cost);
+
+/* ref_2opt_once (src/algorithms/refinment.c:39-93): one best-improvement sweep
+ * over all pairs; applies the move when delta < -1e-7 and adds delta to *cost.
+ * *delta receives the best delta (0 when no improving pair exists). */
+int tspgpu_two_opt_once(tspgpu_ctx *ctx, int *path, double *cost, double *delta);
+
+/* ref_2opt (src/algorithms/refinment.c:3-37): recomputes *cost from the
+ * matrix, then sweeps to the local optimum.  time_left_s < 0 = no deadline
+ * (tsp_env.timelimit == -1); otherwise 4 is returned once it is exceeded,
+ * polled once per batch of sweeps.  *sweeps (may be NULL) counts sweeps, the
+ * final non-improving one included. */
+int tspgpu_two_opt(tspgpu_ctx *ctx, int *path, double *cost, double time_left_s, long *sweeps);
+
+/* tabu_best_move (src/algorithms/metaheuristic.c:188-245): best non-tabu move,
+ * always applied; stamps tabu_list[a,b,succ a,succ b] = iter. */
+int tspgpu_tabu_move(tspgpu_ctx *ctx, int *path, double *cost, int *tabu_list, int tenure, int iter);
+
+/* the k-iteration loop of mh_TabuSearch (src/algorithms/metaheuristic.c:115-166)
+ * with tabu_init (:65-84) and the linear tenure policy (:40-59), resident on
+ * the device.  In: path/cost = the seed.  Out: path/cost = the walk's final
+ * tour, best_path/best_cost = the incumbent (strict <, src/tsp.c:669-676).
+ * trace (may be NULL) receives the k per-iteration costs that the reference
+ * prints to results/TabuResults.dat. */
+int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k,
+                       int *best_path, double *best_cost, double *trace);
+
+/* ---- multi-start entry points ------------------------------------------ */
+
+/* h_Greedy_iterative (src/algorithms/heuristics.c:34-72): NN from every listed
+ * start (starts == NULL: 0..nstarts-1), first strictly-best kept. */
+int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts,
+                  int *best_path, double *best_cost, int *best_start);
+
+/* h_greedy_2opt (src/algorithms/heuristics.c:74-116): NN + 2-opt from every
+ * listed start, all on the device; the winner is the lowest cost, ties to the
+ * earliest entry of `starts`.  last_path/last_cost (may be NULL) receive the
+ * tour of the LAST start, which is what h_Greedy_2opt_mod_costs leaves in
+ * *solution (src/algorithms/heuristics.c:118-149). */
+int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts,
+                              double time_left_s, int *best_path, double *best_cost,
+                              int *best_start, long *total_sweeps,
+                              int *last_path, double *last_cost);
+
+/* ---- device-resident variants (inputs already in HBM; used by bench.py) --- */
+
+/* upload a successor array into tour slot `slot` (0 <= slot < max tours) */
+int tspgpu_tour_load(tspgpu_ctx *ctx, int slot, const int *path);
+/* NN tour built on the device straight into a slot */
+int tspgpu_tour_nn(tspgpu_ctx *ctx, int slot, int start);
+/* copy slot src to slot dst on the device */
+int tspgpu_tour_copy(tspgpu_ctx *ctx, int dst, int src);
+/* sweep slot to its local optimum (max_sweeps < 0: no cap) */
+int tspgpu_tour_two_opt(tspgpu_ctx *ctx, int slot, long max_sweeps, double time_left_s, long *sweeps);
+/* fetch slot's successor array / cost / last delta */
+int tspgpu_tour_store(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta);
+/* launch the sweep kernel alone `reps` times on slot (no move applied) and
+ * return its mean duration in ms from HIP events on the engine's stream */
+int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean);
+/* same for the matrix build kernel */
+int tspgpu_time_build(tspgpu_ctx *ctx, int reps, float *ms_mean);
+/* with TSPGPU_OPT_TIMING: sum of sweep-kernel ms and launch count since reset */
+int tspgpu_timing_read(tspgpu_ctx *ctx, double *sweep_ms_total, long *sweep_launches, int reset);
+/* with TSPGPU_OPT_HISTORY: the recorded moves of slot 0; returns count in *count */
+int tspgpu_history(tspgpu_ctx *ctx, int *a, int *b, double *delta, int capacity, int *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSPGPU_H */

@@ -1,0 +1,102 @@
+/*
+ * oracle/cpu_ref.h -- CPU restatement of the reference's heuristic hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under travellingsalesmanoptimization_amd/
+ * may include, link or dlopen this.  It is used by tests/, by
+ * __graft_entry__.smoke() and by bench.py's cpu_baseline leg as the checker /
+ * the timed CPU baseline, never as a product code path.
+ *
+ * Parity status: PINNED.  Every function below is checked in
+ * tests/test_oracle_golden.py against vectors captured from the reference
+ * itself, compiled unmodified from /root/reference/src by oracle/Makefile into
+ * oracle/_ref/libtspref.so (generator: oracle/make_golden.py, fixtures:
+ * tests/golden/*.json).
+ *
+ * All citations are file:line into the reference checkout.
+ */
+#ifndef TSP_ORACLE_CPU_REF_H
+#define TSP_ORACLE_CPU_REF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* edge weight kinds. EUC_2D is the only one the reference accepts
+ * (src/tsp.c:576-584); ATT and CEIL_2D follow the TSPLIB 95 definitions. */
+enum { ORC_EUC_2D = 0, ORC_ATT = 1, ORC_CEIL_2D = 2 };
+
+/* src/tsp.c:608-636  tsp_compute_costs.  xy = n x {x,y} doubles; out = n*n. */
+int orc_cost_matrix(const double *xy, int n, int kind, double *out);
+
+int orc_cost_rows(const double *xy, int n, int kind, const int *rows, int nrows, double *out);
+
+/* src/tsp.c:468-476 + src/utils/utils.h:23-26  tsp_generate_randompoints
+ * (glibc srand/rand stream). */
+void orc_random_points(int n, int seed, double *xy);
+
+/* src/algorithms/refinment.c:6-9 and src/tsp.c:730-736: sum of c[i][succ[i]]
+ * accumulated for i = 0..n-1 in that order. */
+double orc_tour_cost(const double *c, int n, const int *succ);
+
+/* src/algorithms/refinment.c:39-93  ref_2opt_once.  Returns best delta,
+ * writes the chosen pair to move_ab[0..1] ({-1,-1} when none was found). */
+double orc_two_opt_once(const double *c, int n, int *succ, double *cost,
+                        int *move_ab);
+
+/* src/algorithms/refinment.c:3-37  ref_2opt without deadline / incumbent.
+ * Recomputes *cost first, sweeps until delta >= -1e-7 or max_sweeps (<0: no
+ * cap).  Returns the number of sweeps executed, the final non-improving one
+ * included. */
+long orc_two_opt(const double *c, int n, int *succ, double *cost,
+                 long max_sweeps);
+
+/* src/algorithms/refinment.c:95-114  ref_reverse_path. */
+void orc_reverse_path(int a, int sa, int b, int sb, int *prev, int *succ, int n);
+
+/* src/algorithms/heuristics.c:216-288  h_greedyutil (no deadline). */
+int orc_nn_tour(const double *c, int n, int start, int *succ, double *cost);
+
+/* src/algorithms/heuristics.c:34-72  h_Greedy_iterative: all-start NN, first
+ * strictly best kept.  starts == NULL means 0..nstarts-1. */
+int orc_nn_all(const double *c, int n, const int *starts, int nstarts,
+               int *best_succ, double *best_cost, int *best_start);
+
+/* src/algorithms/heuristics.c:74-116  h_greedy_2opt over an explicit start
+ * list (no deadline): NN + ref_2opt per start, strict-< incumbent
+ * (src/tsp.c:669-676). */
+int orc_multistart_nn_2opt(const double *c, int n, const int *starts,
+                           int nstarts, int *best_succ, double *best_cost,
+                           int *best_start, long *total_sweeps);
+
+/* src/algorithms/metaheuristic.c:188-245 + :416-418  tabu_best_move. */
+int orc_tabu_move(const double *c, int n, int *succ, double *cost,
+                  int *tabu_list, int tenure, int iter, int *move_ab);
+
+/* src/algorithms/metaheuristic.c:65-84 tabu_init, :40-59 tabu_linear_policy,
+ * :115-166 main loop: k iterations starting from (succ,cost); incumbent kept
+ * with strict < (src/tsp.c:669-676).  trace (may be NULL) gets k costs. */
+int orc_tabu_search(const double *c, int n, int *succ, double *cost, int k,
+                    int *best_succ, double *best_cost, double *trace);
+
+/* src/algorithms/metaheuristic.c:344-409 vns_kick + :490-500 case 7; draws
+ * from libc rand().  Out-of-range neighbour probes (the reference reads
+ * tour[-1] / tour[n], metaheuristic.c:372) are treated as "no match". */
+int orc_vns_kick(int n, int *succ);
+
+/* src/algorithms/metaheuristic.c:278-321  VNS loop body: k x (ref_2opt +
+ * r = rand()%9-2 kicks).  best kept with strict <. */
+int orc_vns(const double *c, int n, int *succ, double *cost, int k,
+            int *best_succ, double *best_cost);
+
+/* src/tsp.c:642-667 + :687-728  tsp_validate_solution / tsp_is_tour. */
+int orc_valid_tour(const int *succ, int n);
+
+/* 64-bit FNV-1a over the successor array, one step per node. */
+uint64_t orc_fnv1a(const int *succ, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

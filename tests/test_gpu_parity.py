@@ -1,0 +1,390 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle on the same inputs and
+against the golden vectors captured from the reference.  Bit-exact: integer costs, indices,
+tours; and doubles bit for bit on the float-cost path (the bar in north_star is 1e-6
+relative; the implementation reproduces the reference's operation order, so == is used
+and the tolerance is only the documented fallback)."""
+import numpy as np
+import pytest
+
+from conftest import data_path
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 1e-6  # north_star's bar for float costs; tests below assert exact equality
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import travellingsalesmanoptimization_amd as T
+    e = T.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def T():
+    import travellingsalesmanoptimization_amd as T
+    return T
+
+
+def fx(O, v):
+    return f"{O.fnv1a(v):016x}"
+
+
+def setup(eng, T, O, instances, name, elem, kernel=0):
+    xy, c = instances(name)
+    eng.set_option(T.OPT_ELEM, elem)
+    eng.set_option(T.OPT_KERNEL, kernel)
+    eng.set_points(xy)
+    eng.build_costs()
+    return xy, c
+
+
+# ------------------------------------------------------------------ K1 matrix
+@pytest.mark.parametrize("name", ["berlin52", "kroA100", "pr1002", "n1000_s123", "n64_s7"])
+@pytest.mark.parametrize("elem", [1, 2])
+def test_matrix_bit_exact(eng, T, O, instances, name, elem):
+    xy, c = instances(name)
+    eng.set_option(T.OPT_ELEM, elem)
+    eng.set_points(xy)
+    got = eng.build_costs(fetch=True)
+    assert got.dtype == np.float64 and np.array_equal(got, c)
+    assert eng.info()["elem"] == elem
+
+
+def test_matrix_noninteger_coordinates_usa13509(eng, T, O, golden):
+    """float sqrt of a double sum (tsp.c:629) on non-integer coordinates; full 13509^2 compare
+    against the oracle row by row + the reference's digest"""
+    xy, _ = O.read_tsplib(data_path("usa13509"))
+    eng.set_option(T.OPT_ELEM, 2)
+    eng.set_points(xy)
+    got = eng.build_costs(fetch=True)
+    g = golden["instances"]["usa13509"]["matrix"]
+    assert int(got[g["rows"]].astype(np.int64).sum()) == g["rows_sum"]
+    rows = np.arange(0, len(xy), 97, dtype=np.int32)
+    assert np.array_equal(got[rows], O.cost_rows(xy, rows))
+    assert float(got.sum()) == g["total_sum"]
+    assert np.array_equal(got, got.T)
+
+
+def test_matrix_att_ceil(eng, T, O):
+    xy, _ = O.read_tsplib(data_path("att48"))
+    for kind in (O.ATT, O.CEIL_2D):
+        eng.set_option(T.OPT_ELEM, 0)
+        eng.set_points(xy, kind)
+        assert np.array_equal(eng.build_costs(fetch=True), O.cost_matrix(xy, kind))
+
+
+def test_set_costs_roundtrip_and_kind(eng, T, O, instances):
+    _, c = instances("kroA100")
+    eng.set_option(T.OPT_ELEM, 0)
+    eng.set_costs(c)
+    assert eng.info()["elem"] == 2 and eng.info()["symmetric"] == 1  # integer-valued -> int32 copy
+    assert np.array_equal(eng.get_costs(), c)
+    f = c * 0.37
+    eng.set_costs(f)
+    assert eng.info()["elem"] == 1
+    assert np.array_equal(eng.get_costs(), f)
+    a = c.copy(); a[3, 5] += 1
+    eng.set_costs(a)
+    assert eng.info()["symmetric"] == 0
+
+
+# ------------------------------------------------------------------ K6 NN
+@pytest.mark.parametrize("name", ["berlin52", "kroA100", "pr1002", "n1024_s1"])
+@pytest.mark.parametrize("elem", [1, 2])
+def test_nn_tour(eng, T, O, instances, name, elem):
+    xy, c = setup(eng, T, O, instances, name, elem)
+    n = len(xy)
+    for start in [0, 1, n // 2, n - 1]:
+        succ, cost = eng.nn_tour(start)
+        osucc, ocost = O.nn_tour(c, start)
+        assert cost == ocost and np.array_equal(succ, osucc)
+    with pytest.raises(T.TspGpuError) as ei:
+        eng.nn_tour(n)
+    assert ei.value.code == 14  # UNAVAILABLE, heuristics.c:223-226
+
+
+def test_nn_all_golden(eng, T, O, instances, golden):
+    for key in ["berlin52", "kroA100", "pr1002", "n1000_s123"]:
+        setup(eng, T, O, instances, key, 0)
+        g = golden["algs"][key + "_greedy_iter"]
+        succ, cost, start = eng.nn_all()
+        assert (cost, start, fx(O, succ)) == (g["cost"], g["starting_node"], g["fnv"])
+
+
+# ------------------------------------------------------------------ K2/K4 sweeps
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "n64_s7", "n200_s3"])
+def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel):
+    """every sweep picks the reference's (a,b) and leaves the reference's tour"""
+    xy, c = setup(eng, T, O, instances, name, elem, kernel)
+    succ, cost = O.nn_tour(c, 0)
+    g = succ.copy(); gcost = cost
+    for _ in range(40):
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        gd, gcost = eng.two_opt_once(g, gcost)
+        assert gd == d and gcost == cost and np.array_equal(g, succ), (mv, d, gd)
+        if d >= -1e-7:
+            break
+    assert eng.info()["kernel"] == kernel
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123", "n1024_s1"])
+def test_two_opt_to_local_optimum_golden(eng, T, O, instances, golden, name, elem, kernel):
+    xy, c = setup(eng, T, O, instances, name, elem, kernel)
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    succ, nn_cost = eng.nn_tour(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    eng.set_option(T.OPT_HISTORY, 4096)
+    cost, sweeps, rc = eng.two_opt(succ)
+    assert rc == 0
+    assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+    assert O.valid_tour(succ) and O.tour_cost(c, succ) == cost
+    # the recorded moves replay to the same trace the reference printed
+    a, b, d = eng.history(4096)
+    assert len(a) == sweeps and a[-1] == -1
+    run = nn_cost
+    for i, want in enumerate(g["trace"]):
+        run += d[i]
+        assert run == want
+    eng.set_option(T.OPT_HISTORY, 0)
+
+
+def test_first_moves_survey(eng, T, O, instances):
+    want = {"berlin52": [(10, 50), (28, 45), (0, 20)], "pr1002": [(75, 108), (0, 75), (709, 914)]}
+    for name, moves in want.items():
+        setup(eng, T, O, instances, name, 0)
+        succ, _ = eng.nn_tour(0)
+        eng.set_option(T.OPT_HISTORY, 16)
+        eng.two_opt(succ)
+        a, b, _ = eng.history(16)
+        assert list(zip(a[:3].tolist(), b[:3].tolist())) == moves
+        eng.set_option(T.OPT_HISTORY, 0)
+
+
+@pytest.mark.parametrize("elem", [1, 2])
+def test_full_size_fnl4461(eng, T, O, golden, elem):
+    """BASELINE config 3: iterated 2-opt to the local optimum at n=4461 (603 sweeps; the
+    reference needs 40 s on one core)"""
+    xy, _ = O.read_tsplib(data_path("fnl4461"))
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    g = golden["instances"]["fnl4461"]["two_opt"]
+    succ, nn_cost = eng.nn_tour(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    cost, sweeps, _ = eng.two_opt(succ)
+    assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+
+
+@pytest.mark.parametrize("elem,kernel", [(1, 0), (2, 0), (2, 1)])
+def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel):
+    """the configuration BASELINE.json's metric is quoted on: -n 4096 -seed 123, NN(0) then
+    609 sweeps to 488522 (reference: 48.7 s on one core)"""
+    g = golden["random"]["n4096_s123"]
+    xy = O.random_points(4096, 123)
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel)
+    eng.set_points(xy); eng.build_costs()
+    succ, nn_cost = eng.nn_tour(0)
+    assert nn_cost == g["two_opt"]["nn_cost"]
+    cost, sweeps, _ = eng.two_opt(succ)
+    assert (sweeps, cost, fx(O, succ)) == (g["two_opt"]["sweeps"], g["two_opt"]["final_cost"], g["two_opt"]["final_fnv"])
+    assert O.valid_tour(succ)
+
+
+def test_d18512_five_sweeps(eng, T, O, golden):
+    """BASELINE config 4's instance: n=18512 (int32 matrix 1.4 GB), NN(0) + 5 sweeps"""
+    xy, _ = O.read_tsplib(data_path("d18512"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    g = golden["instances"]["d18512"]["two_opt"]
+    eng.tour_nn(0, 0)
+    succ, nn_cost, _ = eng.tour_store(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    sweeps, _ = eng.tour_two_opt(0, max_sweeps=5)
+    succ, cost, _ = eng.tour_store(0)
+    assert (sweeps, cost, fx(O, succ)) == (5, g["final_cost"], g["final_fnv"])
+
+
+def test_graph_and_eager_agree(eng, T, O, instances):
+    xy, c = setup(eng, T, O, instances, "pr1002", 0)
+    out = []
+    for graph, batch in [(1, 32), (0, 32), (1, 7), (0, 1)]:
+        eng.set_option(T.OPT_GRAPH, graph); eng.set_option(T.OPT_BATCH, batch)
+        succ, _ = eng.nn_tour(5)
+        cost, sweeps, _ = eng.two_opt(succ)
+        out.append((cost, sweeps, fx(O, succ)))
+    eng.set_option(T.OPT_GRAPH, 1); eng.set_option(T.OPT_BATCH, 32)
+    assert len(set(out)) == 1
+    osucc, _ = O.nn_tour(c, 5)
+    osw, ocost = O.two_opt(c, osucc)
+    assert out[0] == (ocost, osw, fx(O, osucc))
+
+
+def test_properties_idempotent_and_valid(eng, T, O, instances):
+    """size-independent properties: a local optimum is a fixed point; tours stay valid;
+    cost equals the node-order recomputation"""
+    xy, c = setup(eng, T, O, instances, "n1024_s1", 0)
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(1024).astype(np.int32)
+    succ = np.empty(1024, dtype=np.int32)
+    succ[perm] = np.roll(perm, -1)
+    o = succ.copy()
+    cost, sweeps, _ = eng.two_opt(succ)
+    osw, ocost = O.two_opt(c, o)
+    assert (cost, sweeps) == (ocost, osw) and np.array_equal(succ, o)
+    cost2, sweeps2, _ = eng.two_opt(succ)
+    assert sweeps2 == 1 and cost2 == cost and np.array_equal(succ, o)
+
+
+def test_invalid_inputs_fail_loudly(eng, T, O, instances):
+    setup(eng, T, O, instances, "berlin52", 0)
+    bad = np.zeros(52, dtype=np.int32)  # not a cycle
+    with pytest.raises(T.TspGpuError) as ei:
+        eng.two_opt(bad)
+    assert ei.value.code == 3
+    two = np.arange(52, dtype=np.int32)
+    two = np.roll(two, -1); two[25] = 0; two[51] = 26  # two sub-cycles
+    with pytest.raises(T.TspGpuError):
+        eng.two_opt(two)
+    with pytest.raises(T.TspGpuError):
+        eng.set_points(np.zeros((3, 2)))  # n < 4: no 2-opt move exists
+
+
+def test_asymmetric_matrix_strict_orientation(eng, T, O):
+    """a non-symmetric caller matrix: only the reference's own orientation b > a is evaluated"""
+    rng = np.random.default_rng(9)
+    n = 96
+    c = rng.integers(1, 1000, size=(n, n)).astype(np.float64)
+    np.fill_diagonal(c, -1.0)
+    for elem in (1, 2):
+        for kernel in (1, 2):
+            eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel)
+            eng.set_costs(c)
+            assert eng.info()["symmetric"] == 0
+            succ, cost = O.nn_tour(c, 0)
+            g = succ.copy()
+            osw, ocost = O.two_opt(c, succ)
+            gcost, gsw, _ = eng.two_opt(g)
+            assert (gcost, gsw) == (ocost, osw) and np.array_equal(g, succ)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+
+
+def test_float_costs_bit_exact(eng, T, O, instances, golden):
+    """the mod-costs regime (heuristics.c:118-149 fed by cplex_model.c:1176-1258): doubles"""
+    for case in golden["mod_costs"]:
+        c = instances(case["instance"])[1]
+        n = c.shape[0]
+        r = np.random.default_rng(case["seed"])
+        x = np.triu(r.random((n, n)), 1); x = x + x.T
+        mc = c * (1.0 - x); np.fill_diagonal(mc, 0.0)
+        mc = np.ascontiguousarray(mc)
+        eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+        eng.set_costs(mc)
+        assert eng.info()["elem"] == 1
+        res = eng.multistart_nn_2opt(want_last=True)
+        # what h_Greedy_2opt_mod_costs leaves in *solution: the LAST start's tour
+        assert float(res["last_cost"]).hex() == case["cost_hex"]
+        assert abs(res["last_cost"] - case["cost"]) <= REL_TOL * abs(case["cost"])
+        assert fx(O, res["last_path"]) == case["fnv"]
+        # every start, against the oracle
+        for s in (0, n // 3):
+            succ, cost = O.nn_tour(mc, s)
+            g, gc = eng.nn_tour(s)
+            assert gc == cost and np.array_equal(g, succ)
+            osw, ocost = O.two_opt(mc, succ)
+            gcost, gsw, _ = eng.two_opt(g)
+            assert float(gcost).hex() == float(ocost).hex() and gsw == osw and np.array_equal(g, succ)
+
+
+# ------------------------------------------------------------------ multi-start
+@pytest.mark.parametrize("key", ["berlin52", "eil51", "kroA100", "n200_s3"])
+def test_multistart_golden(eng, T, O, instances, golden, key):
+    """h_greedy_2opt over all starts = golden 2OPT_GREEDY"""
+    setup(eng, T, O, instances, key, 0)
+    g = golden["algs"][key + "_2opt_greedy"]
+    res = eng.multistart_nn_2opt()
+    assert res["rc"] == 0
+    assert (res["cost"], fx(O, res["path"])) == (g["cost"], g["fnv"])
+
+
+def test_multistart_pr1002_all_starts(eng, T, O, instances, golden):
+    """pr1002, all 1002 starts: 276 s on the reference CPU path; golden 266290"""
+    setup(eng, T, O, instances, "pr1002", 0)
+    g = golden["algs"]["pr1002_2opt_greedy"]
+    res = eng.multistart_nn_2opt()
+    assert (res["cost"], fx(O, res["path"])) == (g["cost"], g["fnv"])
+    assert O.valid_tour(res["path"])
+
+
+def test_multistart_subset_and_chunks(eng, T, O, instances):
+    xy, c = setup(eng, T, O, instances, "n200_s3", 0)
+    starts = np.array([7, 199, 0, 33, 34, 150, 3], dtype=np.int32)
+    want = O.multistart_nn_2opt(c, starts)
+    for cap in (1024, 3):
+        eng.set_option(T.OPT_MAX_TOURS, cap)
+        res = eng.multistart_nn_2opt(starts)
+        assert (res["cost"], res["start"], res["sweeps"]) == (want[1], want[2], want[3])
+        assert np.array_equal(res["path"], want[0])
+    eng.set_option(T.OPT_MAX_TOURS, 1024)
+
+
+def test_deadline_returns_code_4_with_valid_tour(eng, T, O, instances):
+    xy, c = setup(eng, T, O, instances, "pr1002", 0)
+    eng.set_option(T.OPT_BATCH, 1)
+    succ, nn_cost = eng.nn_tour(0)
+    cost, sweeps, rc = eng.two_opt(succ, time_left_s=0.0)
+    eng.set_option(T.OPT_BATCH, 32)
+    assert rc == 4 and 1 <= sweeps < 169
+    assert O.valid_tour(succ) and O.tour_cost(c, succ) == cost and cost < nn_cost
+
+
+# ------------------------------------------------------------------ K3 tabu
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2])
+def test_tabu_move_golden(eng, T, O, instances, golden, elem, kernel):
+    for case in golden["tabu_move"]:
+        xy, c = setup(eng, T, O, instances, case["instance"], elem, kernel)
+        n = len(xy)
+        succ, cost = O.nn_tour(c, 0)
+        tl = np.full(n, -1, dtype=np.int32)
+        for it, want in enumerate(case["steps"]):
+            cost = eng.tabu_move(succ, cost, tl, case["tenure"], it)
+            assert (cost, fx(O, succ), fx(O, tl)) == (want["cost"], want["fnv"], want["tabu_fnv"])
+
+
+@pytest.mark.parametrize("key", ["berlin52", "eil51", "kroA100"])
+def test_tabu_search_golden(eng, T, O, instances, golden, key):
+    xy, c = setup(eng, T, O, instances, key, 0)
+    g = golden["algs"][key + "_tabu_k200"]
+    res = eng.multistart_nn_2opt()
+    seed, cost = res["path"], res["cost"]
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 200, want_trace=True)
+    assert (best_cost, fx(O, best)) == (g["cost"], g["fnv"])
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, 200)
+    assert np.array_equal(trace, otrace) and final == ofinal and np.array_equal(seed, oseed)
+
+
+def test_vns_with_host_kicks(eng, T, O, instances, golden):
+    """mh_VNS: 2-opt on the device, kicks on the host from glibc rand() (oracle's restatement
+    of vns_kick supplies the kick in this test)"""
+    for key in ["berlin52", "kroA100"]:
+        xy, c = setup(eng, T, O, instances, key, 0)
+        g = golden["algs"][key + "_vns_k200"]
+        succ, cost, _ = eng.nn_all()
+        best, best_cost = succ.copy(), cost
+        O.libc_srand(1)
+        import ctypes
+        libc = ctypes.CDLL(None)
+        for _ in range(200):
+            cost, _, _ = eng.two_opt(succ)
+            if cost < best_cost:
+                best_cost, best = cost, succ.copy()
+            r = libc.rand() % 9 - 2
+            for _ in range(r):
+                O.vns_kick(succ)
+        assert (best_cost, fx(O, best)) == (g["cost"], g["fnv"])

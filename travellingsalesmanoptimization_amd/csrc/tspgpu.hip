@@ -1,0 +1,1681 @@
+// tspgpu.hip -- MI355X (gfx950 / CDNA4) 2-opt local-search engine: kernels + C ABI.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off -fPIC -shared
+//        (see csrc/Makefile; -ffp-contract=off keeps dx*dx+dy*dy as two rounded
+//        multiplies and one add, like the reference binary -- SURVEY 7, hard part 2)
+//
+// What runs here, and the reference loop each kernel takes over (file:line in
+// the reference checkout):
+//   k_build_costs   src/tsp.c:616-633              n x n rounded-Euclidean matrix
+//   k_nn            src/algorithms/heuristics.c:216-288   nearest-neighbour tour
+//   k_tour_init     src/algorithms/refinment.c:6-9,43-46  cost recompute, prev/pos
+//   k_sweep_*       src/algorithms/refinment.c:49-69      full pair scan, argmin
+//                   src/algorithms/metaheuristic.c:198-222 (TABU variant)
+//   k_apply         src/algorithms/refinment.c:74-86,95-114  apply best move
+//                   src/algorithms/metaheuristic.c:226-240,40-59 (TABU variant)
+//
+// Tour representation on the device: position array ord[p] (+ inverse pos[],
+// successor succ[] and dnext[b] = c[b][succ b]).  A 2-opt move (a,b) reverses
+// the cyclic position range pos[a]+1 .. pos[b], which is exactly the segment
+// succ_a .. b that ref_reverse_path flips, so the successor direction -- and
+// with it every later (a,b) label and tie-break -- matches the reference.
+//
+// Argmin order: the reference scans a ascending, b ascending and keeps the
+// first strictly smallest delta, i.e. it minimises the key (delta, a, b).  Here
+// every workgroup minimises that same key over its share of the pairs, so the
+// scan order on the device is free.
+//
+// There is no CPU fallback anywhere in this file.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cfloat>
+#include <climits>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "tspgpu.h"
+
+// reference ERROR_CODE numbering (src/utils/errors.h:33-51)
+enum { E_OK = 0, E_INVALID = 3, E_DEADLINE = 4, E_EXHAUSTED = 8, E_PRECOND = 9,
+       E_UNIMPL = 12, E_INTERNAL = 13, E_UNAVAILABLE = 14 };
+
+#define TWO_OPT_EPS (-1.0E-7) /* src/tsp.h:19 */
+
+typedef unsigned long long u64;
+
+static constexpr u64 KEY_NONE = ~0ull;
+static constexpr int MAX_WGS_PER_TOUR = 1024;
+
+struct Partial {
+    double d;
+    u64 key; // (lo << 32) | hi, KEY_NONE when the workgroup found nothing
+};
+
+// ---------------------------------------------------------------------------
+// element traits: the matrix is held either as doubles (any caller matrix) or
+// as an exact int32 copy (every integer-valued matrix: EUC_2D, ATT, CEIL_2D)
+// ---------------------------------------------------------------------------
+typedef double v2f64 __attribute__((ext_vector_type(2)));
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct Elem;
+template <> struct Elem<double> {
+    typedef v2f64 vec;
+    static constexpr int V = 2;
+    __device__ static double lim() { return DBL_MAX; }
+};
+template <> struct Elem<int> {
+    typedef v4i32 vec;
+    static constexpr int V = 4;
+    __device__ static int lim() { return INT_MAX; }
+};
+
+__device__ __forceinline__ double vget(const v2f64 &v, int i) { return v[i]; }
+__device__ __forceinline__ int vget(const v4i32 &v, int i) { return v[i]; }
+
+__device__ __forceinline__ bool key_better(double d1, u64 k1, double d2, u64 k2)
+{
+    return d1 < d2 || (d1 == d2 && k1 < k2);
+}
+
+// block-wide lexicographic min of (d, key); result valid in every thread.
+// scratch: 2 * 16 Partial-sized slots.
+__device__ __forceinline__ void block_argmin(double &d, u64 &key, Partial *scratch)
+{
+    for (int off = 32; off > 0; off >>= 1) {
+        double od = __shfl_xor(d, off);
+        u64 ok = __shfl_xor(key, off);
+        if (key_better(od, ok, d, key)) { d = od; key = ok; }
+    }
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { scratch[w].d = d; scratch[w].key = key; }
+    __syncthreads();
+    d = scratch[0].d; key = scratch[0].key;
+    for (int i = 1; i < nw; i++) {
+        double od = scratch[i].d; u64 ok = scratch[i].key;
+        if (key_better(od, ok, d, key)) { d = od; key = ok; }
+    }
+    __syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// K1: cost matrix.  grid (ceil(ld / (256*V)), n): one row per blockIdx.y, each
+// thread stores one 16-byte vector.  Write-bound: sizeof(T) * n * ld bytes.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double edge_weight(double ax, double ay, double bx, double by, int kind)
+{
+    // src/tsp.c:629: (double)((int)(sqrtf(pow(dx,2)+pow(dy,2)) + 0.5)); the sum is a
+    // double, sqrtf takes it narrowed to float, the root is widened before +0.5.
+    double dx = bx - ax, dy = by - ay;
+    double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
+    if (kind == TSPGPU_EUC_2D) {
+        float root = __builtin_sqrtf((float)sq); // correctly rounded (hipcc default)
+        return (double)((int)((double)root + 0.5));
+    }
+    if (kind == TSPGPU_ATT) { // TSPLIB 95
+        double r = __builtin_sqrt(sq / 10.0);
+        double t = (double)(long long)(r + 0.5);
+        return t < r ? t + 1.0 : t;
+    }
+    return __builtin_ceil(__builtin_sqrt(sq)); // CEIL_2D
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__ pts, int n, int ld, int kind,
+                                                     T *__restrict__ out)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    const int i = blockIdx.y;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (j0 >= ld) return;
+    const double2 pi = pts[i];
+    T v[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        const int j = j0 + k;
+        if (j >= n) v[k] = (T)0;
+        else if (j == i) v[k] = (T)-1;
+        else {
+            const double2 pj = pts[j];
+            v[k] = (T)edge_weight(pi.x, pi.y, pj.x, pj.y, kind);
+        }
+    }
+    VT o;
+#pragma unroll
+    for (int k = 0; k < V; k++) o[k] = v[k];
+    *reinterpret_cast<VT *>(out + (size_t)i * ld + j0) = o;
+}
+
+// ingest of a caller matrix: flags[0] = some entry is not an int in [-1, 2^28),
+// flags[1] = some c[i][j] != c[j][i]
+__global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, int n, int ld, int *flags)
+{
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const double x = m[(size_t)i * ld + j];
+    const double r = __builtin_trunc(x);
+    if (!(r == x && x >= -1.0 && x < 268435456.0)) flags[0] = 1;
+    if (j > i && m[(size_t)j * ld + i] != x) flags[1] = 1;
+}
+
+__global__ void __launch_bounds__(256) k_f64_to_i32(const double *__restrict__ m, int n, int ld, int *__restrict__ out)
+{
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ld) return;
+    out[(size_t)i * ld + j] = j < n ? (int)m[(size_t)i * ld + j] : 0;
+}
+
+__global__ void __launch_bounds__(256) k_i32_to_f64(const int *__restrict__ m, int n, int ld, double *__restrict__ out)
+{
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= ld) return;
+    out[(size_t)i * ld + j] = j < n ? (double)m[(size_t)i * ld + j] : 0.0;
+}
+
+// ---------------------------------------------------------------------------
+// tour state (structure of arrays over tour slots)
+// ---------------------------------------------------------------------------
+struct Tours {
+    int *ord, *pos, *succ;   // [cap][n]
+    double *dnext;           // [cap][n] 8-byte slots; int32 mode uses the first 4n bytes of each
+    double *cost, *last_delta; // [cap]
+    int *done, *nsweeps, *cap_sweeps, *status; // [cap]
+    Partial *partial;        // [cap][MAX_WGS_PER_TOUR]
+};
+
+struct TabuState {           // device-resident, slot 0 only
+    int iter, tenure, t_min, t_max, up, resident;
+    double best_cost;
+};
+
+struct HistBuf { int *a, *b; double *d; int cap; };
+
+template <typename T>
+__device__ __forceinline__ T *dnext_of(const Tours &S, int t, int n)
+{
+    return reinterpret_cast<T *>(S.dnext + (size_t)t * n);
+}
+
+// ---------------------------------------------------------------------------
+// k_tour_init: ord[] given; derive pos/succ/dnext and the cost exactly as
+// ref_2opt recomputes it (src/algorithms/refinment.c:6-9): sum over NODE index
+// i = 0..n-1 of c[i][succ i], accumulated in that order (doubles), so that
+// non-integer matrices give the same bits.  One workgroup per tour.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict__ mat, int n, int ld, int slot0,
+                                                    const int *__restrict__ caps)
+{
+    __shared__ double chunk[1024];
+    const int t = slot0 + blockIdx.x;
+    const int *ord = S.ord + (size_t)t * n;
+    int *pos = S.pos + (size_t)t * n, *succ = S.succ + (size_t)t * n;
+    T *dn = dnext_of<T>(S, t, n);
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        const int node = ord[p];
+        const int s = ord[p + 1 == n ? 0 : p + 1];
+        pos[node] = p;
+        succ[node] = s;
+        dn[node] = mat[(size_t)node * ld + s];
+    }
+    __syncthreads();
+    double total = 0;
+    if constexpr (sizeof(T) == 4) {
+        long long part = 0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) part += dn[i];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+        long long *acc = reinterpret_cast<long long *>(chunk);
+        if ((threadIdx.x & 63) == 0) acc[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long s = 0;
+            for (int w = 0; w < (int)((blockDim.x + 63) >> 6); w++) s += acc[w];
+            total = (double)s;
+        }
+    } else {
+        for (int base = 0; base < n; base += 1024) {
+            const int m = min(1024, n - base);
+            for (int i = threadIdx.x; i < m; i += blockDim.x) chunk[i] = dn[base + i];
+            __syncthreads();
+            if (threadIdx.x == 0)
+                for (int i = 0; i < m; i++) total += chunk[i];
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) {
+        S.cost[t] = total;
+        S.last_delta[t] = 0;
+        S.done[t] = 0;
+        S.nsweeps[t] = 0;
+        S.cap_sweeps[t] = caps ? caps[blockIdx.x] : -1;
+        S.status[t] = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K6: nearest-neighbour tour, one workgroup per start.  Thread tid owns nodes
+// tid, tid+BT, ... (coalesced row reads) and keeps their visited bits in a
+// register mask (n <= 64*BT).  Each step: masked row argmin by (weight, index)
+// -> ties go to the lowest index, as the strict < of heuristics.c:258.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat, int n, int ld, int slot0,
+                                             const int *__restrict__ starts)
+{
+    __shared__ Partial red[2][16];
+    const int t = slot0 + blockIdx.x;
+    const int start = starts[blockIdx.x];
+    int *ord = S.ord + (size_t)t * n;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nw = (BT + 63) >> 6;
+    u64 seen = 0; // bit k <-> node tid + k*BT
+    if (start % BT == tid) seen |= 1ull << (start / BT);
+    int cur = start;
+    double total = 0;
+    if (tid == 0) ord[0] = start;
+    int step = 1;
+    for (; step < n; step++) {
+        const T *row = mat + (size_t)cur * ld;
+        double lo = DBL_MAX;
+        u64 arg = KEY_NONE;
+        for (int k = 0, i = tid; i < n; i += BT, k++) {
+            if ((seen >> k) & 1) continue;
+            const double w = (double)row[i];
+            if (w != -1.0 && w < lo) { lo = w; arg = (u64)i; } // NOT_CONNECTED, utils.h:35
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double od = __shfl_xor(lo, off);
+            u64 oa = __shfl_xor(arg, off);
+            if (key_better(od, oa, lo, arg)) { lo = od; arg = oa; }
+        }
+        Partial *r = red[step & 1];
+        if ((tid & 63) == 0) { r[tid >> 6].d = lo; r[tid >> 6].key = arg; }
+        __syncthreads();
+        lo = r[0].d; arg = r[0].key;
+        for (int w = 1; w < nw; w++)
+            if (key_better(r[w].d, r[w].key, lo, arg)) { lo = r[w].d; arg = r[w].key; }
+        if (arg == KEY_NONE) break; // nothing reachable: heuristics.c:268-272 closes the path here
+        const int nxt = (int)arg;
+        if (nxt % BT == tid) seen |= 1ull << (nxt / BT);
+        if (tid == 0) { ord[step] = nxt; total += lo; }
+        cur = nxt;
+    }
+    if (tid == 0) {
+        total += (double)mat[(size_t)cur * ld + start]; // heuristics.c:281
+        S.cost[t] = total;
+        S.status[t] = (step == n) ? 0 : 1; // 1: tour left incomplete
+    }
+}
+
+// ---------------------------------------------------------------------------
+// sweep arguments
+// ---------------------------------------------------------------------------
+struct SweepArgs {
+    Tours S;
+    const void *mat;
+    int n, ld, slot0, P;     // P = tour positions per workgroup
+    int symmetric;
+    const int *tabu_list;    // TABU only
+    const TabuState *tabu;   // TABU only
+};
+
+// acceptance rule for the pair {a,b} seen from a's workgroup.  Symmetric
+// matrices: each unordered pair is owned by exactly one of its two workgroups
+// (the one from which the other node is at most half way round the INDEX
+// circle), which balances the triangular loop of refinment.c:49-50 perfectly.
+// Otherwise only the reference's own orientation b > a is evaluated.
+__device__ __forceinline__ bool pair_owned(int a, int b, int n, int symmetric)
+{
+    if (!symmetric) return b > a;
+    int k = b - a;
+    if (k < 0) k += n;
+    const int k2 = 2 * k;
+    return k2 < n || (k2 == n && a < b);
+}
+
+template <typename DT>
+__device__ __forceinline__ void consider(DT delta, int a, int b, DT &best_d, u64 &best_key)
+{
+    if (delta <= best_d) {
+        const u64 key = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+        if (delta < best_d || key < best_key) { best_d = delta; best_key = key; }
+    }
+}
+
+__device__ __forceinline__ bool is_tabu(const int *tl, int node, int iter, int tenure)
+{
+    const int s = tl[node];
+    return iter - s < tenure && s != -1; // metaheuristic.c:416-418
+}
+
+// ---------------------------------------------------------------------------
+// K2/K3 "simple" sweep: one LDS row.  Workgroup g walks tour positions
+// [g*P, (g+1)*P); for position p: a = ord[p], sa = ord[p+1].  Row sa is staged
+// in LDS (gather target c[sa][sb]); row a is read coalesced from global; succ[]
+// and dnext[] come from L2.  Used when three rows do not fit in LDS, and as an
+// independent cross-check of the pipelined kernel.
+// ---------------------------------------------------------------------------
+template <typename T, bool TABU>
+__global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = A.n, ld = A.ld;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    T *rowS = reinterpret_cast<T *>(smem);
+    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)ld * sizeof(T));
+    const T *mat = static_cast<const T *>(A.mat);
+    const int *ord = A.S.ord + (size_t)t * n;
+    const int *succ = A.S.succ + (size_t)t * n;
+    const T *dn = dnext_of<T>(A.S, t, n);
+
+    int iter = 0, tenure = 0;
+    if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
+
+    T best_d = TABU ? Elem<T>::lim() : (T)0;
+    u64 best_key = TABU ? KEY_NONE : 0; // key 0 cannot be beaten on a tie: "no move" is (0, 0)
+
+    const int p0 = blockIdx.x * A.P;
+    const int cnt = min(A.P, n - p0);
+    for (int s = 0; s < cnt; s++) {
+        const int p = p0 + s;
+        const int a = ord[p];
+        const int sa = ord[p + 1 == n ? 0 : p + 1];
+        __syncthreads();
+        {
+            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)sa * ld);
+            VT *dst = reinterpret_cast<VT *>(rowS);
+            for (int i = tid; i < ld / V; i += BT) dst[i] = src[i];
+        }
+        __syncthreads();
+        if constexpr (TABU) {
+            if (is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure)) continue;
+        }
+        const T d_a = dn[a];
+        const T *rowA = mat + (size_t)a * ld;
+        const int kmax = A.symmetric ? n / 2 : n - 1 - a;
+        for (int k = 1 + tid; k <= kmax; k += BT) {
+            int b = a + k;
+            if (b >= n) b -= n;
+            const int sb = succ[b];
+            if (b == sa || sb == a) continue;          // refinment.c:55
+            if (!pair_owned(a, b, n, A.symmetric)) continue;
+            if constexpr (TABU) {
+                if (is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure)) continue;
+            }
+            const T made = rowA[b] + rowS[sb];         // c[a][b] + c[sa][sb]
+            const T kept = d_a + dn[b];                // c[a][sa] + c[b][sb]
+            consider<T>(made - kept, a, b, best_d, best_key);
+        }
+    }
+    double d = (double)best_d;
+    u64 key = best_key;
+    __syncthreads();
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2/K3 "pipelined" sweep: the speed-of-light form for rows that fit LDS three
+// times.  Workgroup g walks a run of cnt consecutive tour positions and needs
+// the cnt+1 matrix rows of the nodes on that run, each exactly once:
+//     row r   (node a)  : c[a][b], read conflict-free from LDS at the thread's
+//                         OWN b's (b fixed per thread for the whole kernel, so
+//                         succ[b], dnext[b] live in registers)
+//     row r+1 (node sa) : c[sa][succ b], random LDS gather
+//     row r+2, r+3      : in flight from HBM in registers (two rows deep),
+//                         written to the third LDS buffer at the end of the step
+// so every matrix byte is fetched once per sweep (+1 row per run) with 16-byte
+// coalesced loads, and one barrier separates steps.  Both orientations of a
+// pair meet in LDS; pair_owned() keeps one.
+// ---------------------------------------------------------------------------
+template <typename T, int NCH, bool TABU>
+__global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = A.n, ld = A.ld;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V; // 16-byte vectors per row
+
+    T *buf = reinterpret_cast<T *>(smem);                                  // 3 * ld
+    int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)); // P + 1 (+pad)
+    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + (size_t)((A.P + 1 + 3) & ~3) * 4);
+
+    const T *mat = static_cast<const T *>(A.mat);
+    const int *ord = A.S.ord + (size_t)t * n;
+    const int *succ = A.S.succ + (size_t)t * n;
+    const T *dnx = dnext_of<T>(A.S, t, n);
+
+    int iter = 0, tenure = 0;
+    if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
+
+    const int p0 = blockIdx.x * A.P;
+    const int cnt = min(A.P, n - p0);
+    // (host guarantees cnt >= 1 for every launched workgroup)
+    for (int i = tid; i <= cnt; i += BT) {
+        int p = p0 + i;
+        if (p >= n) p -= n;
+        nodes[i] = ord[p];
+    }
+
+    // per-thread state of the owned b's
+    int sbv[NCH][V];
+    T dnv[NCH][V];
+    bool skipb[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            if (b < n) {
+                const int s = succ[b];
+                sbv[c][v] = s;
+                dnv[c][v] = dnx[b];
+                bool sk = false;
+                if constexpr (TABU) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, s, iter, tenure);
+                skipb[c][v] = sk;
+            } else {
+                sbv[c][v] = 0; dnv[c][v] = 0; skipb[c][v] = true;
+            }
+        }
+    }
+    __syncthreads(); // nodes[] visible
+
+    VT R0[NCH], R1[NCH];
+    auto issue = [&](VT(&R)[NCH], int r) __attribute__((always_inline)) {
+        // branch-free: lanes past the row end re-read its last vector (and later
+        // re-write the same bytes), which keeps R[] in registers
+        // Past the end of the run (r > cnt) every lane re-reads one hot vector instead:
+        // the number of loads in flight is then the same on every path, which lets
+        // hipcc place exact counted vmcnt waits in front of the LDS writes.
+        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
+        const int lim = r <= cnt ? nvec - 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) R[c] = src[min(c * BT + tid, lim)];
+    };
+    auto land = [&](const VT(&R)[NCH], int slot) __attribute__((always_inline)) {
+        VT *dst = reinterpret_cast<VT *>(buf + (size_t)slot * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[c];
+    };
+
+    issue(R0, 0);
+    issue(R1, 1);
+    land(R0, 0);
+    land(R1, 1);
+    issue(R0, 2);
+    issue(R1, 3);
+    __syncthreads();
+
+    T best_d = TABU ? Elem<T>::lim() : (T)0;
+    u64 best_key = TABU ? KEY_NONE : 0;
+
+    const int half = n / 2;
+    auto step = [&](int s, VT(&R)[NCH]) __attribute__((always_inline)) {
+        const int a = nodes[s], sa = nodes[s + 1];
+        const T *bA = buf + (size_t)(s % 3) * ld;
+        const T *bS = buf + (size_t)((s + 1) % 3) * ld;
+        bool live = true;
+        if constexpr (TABU) live = !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        if (live) {
+            const T d_a = bA[sa]; // c[a][sa]
+            // index range (cyclic) that pair_owned() can accept from a: [a+1, a+half] / (a, n)
+            const int lo = a + 1;
+            const int hi = A.symmetric ? a + half : n - 1;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const int w0 = (c * BT + (tid & ~63)) * V;      // this wave's first b in chunk c
+                const int w1 = w0 + 64 * V - 1;
+                const bool hit = hi < n ? (w0 <= hi && w1 >= lo) : (w1 >= lo || w0 <= hi - n);
+                if (!hit) continue;                             // wave-uniform
+                const int b0 = (c * BT + tid) * V;
+                // all LDS reads of the chunk first (lanes past the row read its last vector;
+                // their results are masked by skipb), then branch-free arithmetic
+                const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
+                T g[V];
+#pragma unroll
+                for (int v = 0; v < V; v++) g[v] = bS[sbv[c][v]];
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    const int b = b0 + v;
+                    const int sb = sbv[c][v];
+                    const T made = vget(xa, v) + g[v];          // c[a][b] + c[sa][sb]
+                    const T kept = d_a + dnv[c][v];             // c[a][sa] + c[b][sb]
+                    const T delta = made - kept;
+                    int k = b - a;
+                    k += (k >> 31) & n;                         // (b - a) mod n
+                    const int k2 = 2 * k;
+                    const bool mine = A.symmetric ? ((k2 < n) | ((k2 == n) & (a < b))) : (b > a);
+                    const bool ok = (!skipb[c][v]) & (k != 0) & (b != sa) & (sb != a) & mine & (delta <= best_d);
+                    if (ok) consider<T>(delta, a, b, best_d, best_key);
+                }
+            }
+        }
+        if (s + 2 <= cnt) land(R, (s + 2) % 3);
+        issue(R, s + 4);
+        __syncthreads();
+    };
+
+    {
+        int s = 0;
+        for (; s + 1 < cnt; s += 2) { // unconditional body: exact vmcnt accounting
+            step(s, R0);
+            step(s + 1, R1);
+        }
+        if (s < cnt) step(s, R0);
+    }
+
+    double d = (double)best_d;
+    u64 key = best_key;
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K4 apply: one workgroup per tour.  Reduces the per-workgroup partials to the
+// global (delta, a, b), applies the move as a cyclic reversal of positions
+// pos[a]+1 .. pos[b] (= ref_reverse_path's segment succ_a .. b), refreshes
+// succ/dnext on the touched span, updates cost, sweep counter, done flag.
+// TABU: always applies the best admissible move, stamps the tabu list, keeps
+// the incumbent and advances the linear tenure policy.
+// ---------------------------------------------------------------------------
+struct ApplyArgs {
+    Tours S;
+    const void *mat;
+    int n, ld, slot0, G;
+    int *tabu_list;      // TABU
+    TabuState *tabu;     // TABU
+    int *best_succ;      // TABU resident incumbent
+    double *trace;       // TABU resident per-iteration costs (may be null)
+    HistBuf hist;        // slot 0 move history (cap 0 = off)
+};
+
+template <typename T, bool TABU>
+__global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
+{
+    __shared__ Partial scratch[16];
+    const int n = A.n, ld = A.ld;
+    const int t = A.slot0 + blockIdx.x;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const T *mat = static_cast<const T *>(A.mat);
+
+    double d = TABU ? DBL_MAX : 0.0;
+    u64 key = TABU ? KEY_NONE : 0;
+    const Partial *part = A.S.partial + (size_t)t * MAX_WGS_PER_TOUR;
+    for (int g = tid; g < A.G; g += BT) {
+        const Partial q = part[g];
+        if (key_better(q.d, q.key, d, key)) { d = q.d; key = q.key; }
+    }
+    block_argmin(d, key, scratch);
+
+    const int sweeps_now = A.S.nsweeps[t] + 1;
+    const int cap = A.S.cap_sweeps[t];
+    const bool move = TABU ? (key != KEY_NONE) : (d < TWO_OPT_EPS);
+    const int a = (int)(key >> 32), b = (int)(key & 0xffffffffu);
+
+    int *ord = A.S.ord + (size_t)t * n, *pos = A.S.pos + (size_t)t * n, *succ = A.S.succ + (size_t)t * n;
+    int sa = -1, sb = -1;
+    if (move) {
+        const int i = pos[a], j = pos[b];
+        sa = succ[a]; sb = succ[b];
+        int L = j - i;
+        if (L < 0) L += n; // positions i+1 .. i+L hold succ_a .. b
+        __syncthreads();   // everybody has read pos/succ before they change
+        for (int k = tid; k < L / 2; k += BT) {
+            int p = i + 1 + k; if (p >= n) p -= n;
+            int q = j - k;     if (q < 0) q += n;
+            const int u = ord[p], v = ord[q];
+            ord[p] = v; ord[q] = u;
+            pos[v] = p; pos[u] = q;
+        }
+        __syncthreads();
+        T *dn = dnext_of<T>(A.S, t, n);
+        for (int k = tid; k <= L; k += BT) { // a, the reversed span; its last node now precedes sb
+            int p = i + k; if (p >= n) p -= n;
+            const int node = ord[p];
+            const int s = ord[p + 1 == n ? 0 : p + 1];
+            succ[node] = s;
+            dn[node] = mat[(size_t)node * ld + s];
+        }
+    }
+    if constexpr (TABU) {
+        TabuState *ts = A.tabu;
+        const int iter = ts->iter;
+        double cost_now = A.S.cost[t];
+        if (move) cost_now += d;
+        const bool improved = ts->resident && cost_now < ts->best_cost;
+        __syncthreads(); // succ[] final; all threads have read ts->iter / best_cost
+        if (improved && A.best_succ)
+            for (int k = tid; k < n; k += BT) A.best_succ[k] = succ[k];
+        if (tid == 0) {
+            if (move) {
+                A.S.cost[t] = cost_now;
+                A.tabu_list[a] = iter; A.tabu_list[b] = iter; A.tabu_list[sa] = iter; A.tabu_list[sb] = iter;
+            }
+            A.S.last_delta[t] = move ? d : 0.0;
+            if (improved) ts->best_cost = cost_now;
+            if (ts->resident && A.trace) A.trace[iter] = cost_now;
+            // next iteration: linear policy, metaheuristic.c:40-59
+            int tenure = ts->tenure, up = ts->up;
+            if (tenure == ts->t_max || tenure == ts->t_min) up = !up;
+            tenure += up ? 1 : -1;
+            ts->tenure = tenure; ts->up = up; ts->iter = iter + 1;
+            A.S.nsweeps[t] = sweeps_now;
+            if (cap >= 0 && sweeps_now >= cap) A.S.done[t] = 1;
+        }
+    } else {
+        if (tid == 0) {
+            if (move) A.S.cost[t] += d;
+            A.S.last_delta[t] = d;
+            A.S.nsweeps[t] = sweeps_now;
+            if (!move || (cap >= 0 && sweeps_now >= cap)) A.S.done[t] = 1;
+            if (t == 0 && sweeps_now <= A.hist.cap) {
+                A.hist.a[sweeps_now - 1] = move ? a : -1;
+                A.hist.b[sweeps_now - 1] = move ? b : -1;
+                A.hist.d[sweeps_now - 1] = d;
+            }
+        }
+    }
+}
+
+__global__ void k_copy_tour(Tours S, int n, int dst, int src)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        S.ord[(size_t)dst * n + i] = S.ord[(size_t)src * n + i];
+        S.pos[(size_t)dst * n + i] = S.pos[(size_t)src * n + i];
+        S.succ[(size_t)dst * n + i] = S.succ[(size_t)src * n + i];
+        S.dnext[(size_t)dst * n + i] = S.dnext[(size_t)src * n + i];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        S.cost[dst] = S.cost[src]; S.last_delta[dst] = S.last_delta[src];
+        S.done[dst] = S.done[src]; S.nsweeps[dst] = S.nsweeps[src];
+        S.cap_sweeps[dst] = S.cap_sweeps[src]; S.status[dst] = S.status[src];
+    }
+}
+
+__global__ void k_rearm(Tours S, int slot0, int count, int cap)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) { S.done[slot0 + i] = 0; S.nsweeps[slot0 + i] = 0; S.cap_sweeps[slot0 + i] = cap; }
+}
+
+// ===========================================================================
+// host side
+// ===========================================================================
+struct GraphEntry { int slot0, ntours, tabu, K; hipGraphExec_t exec; };
+
+struct tspgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int cus = 256;
+    size_t lds_max = 65536;
+    std::string err;
+
+    // options
+    int opt_elem = TSPGPU_ELEM_AUTO, opt_kernel = 0, opt_batch = 32, opt_wgs = 0, opt_hist = 0, opt_graph = 1,
+        opt_timing = 0, opt_block = 0, opt_max_tours = 1024;
+
+    // instance
+    int n = 0, ld = 0, kind = TSPGPU_EUC_2D;
+    bool have_points = false, have_costs = false, symmetric = true;
+    int elem = 0; // TSPGPU_ELEM_F64 / _I32 in use
+    double2 *d_pts = nullptr;
+    double *d_f64 = nullptr; // [n][ld], present when elem == F64 (or transiently)
+    int *d_i32 = nullptr;    // [n][ld], present when elem == I32
+    int *d_flags = nullptr;
+
+    // tours
+    int tcap = 0;
+    Tours S{};
+    int *d_starts = nullptr, *d_caps = nullptr;
+    int *h_status = nullptr; // pinned: done[tcap] then nsweeps[tcap]
+    double *h_costs = nullptr; // pinned [tcap]
+
+    // tabu
+    int *d_tabu_list = nullptr, *d_best_succ = nullptr;
+    TabuState *d_tabu = nullptr;
+    double *d_trace = nullptr; int trace_cap = 0;
+
+    // history
+    HistBuf hist{nullptr, nullptr, nullptr, 0};
+
+    // launch plan
+    int plan_kernel = 0, plan_G = 0, plan_P = 0, plan_BT = 0, plan_NCH = 0, plan_T = 0;
+    size_t plan_lds = 0;
+
+    std::vector<GraphEntry> graphs;
+
+    // timing
+    std::vector<hipEvent_t> ev;
+    double sweep_ms_total = 0; long sweep_launches = 0;
+};
+
+static int fail(tspgpu_ctx *c, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return fail(ctx, E_INTERNAL, "%s -> %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+static void drop_graphs(tspgpu_ctx *ctx)
+{
+    for (auto &g : ctx->graphs) hipGraphExecDestroy(g.exec);
+    ctx->graphs.clear();
+}
+
+static void free_matrix(tspgpu_ctx *ctx)
+{
+    if (ctx->d_f64) hipFree(ctx->d_f64);
+    if (ctx->d_i32) hipFree(ctx->d_i32);
+    ctx->d_f64 = nullptr; ctx->d_i32 = nullptr; ctx->have_costs = false;
+    drop_graphs(ctx);
+}
+
+static void free_tours(tspgpu_ctx *ctx)
+{
+    Tours &S = ctx->S;
+    void *ptrs[] = {S.ord, S.pos, S.succ, S.dnext, S.cost, S.last_delta, S.done, S.nsweeps, S.cap_sweeps, S.status,
+                    S.partial, ctx->d_starts, ctx->d_caps, ctx->d_tabu_list, ctx->d_best_succ, ctx->d_tabu};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->h_costs) hipHostFree(ctx->h_costs);
+    memset(&S, 0, sizeof S);
+    ctx->d_starts = ctx->d_caps = ctx->d_tabu_list = ctx->d_best_succ = nullptr;
+    ctx->d_tabu = nullptr; ctx->h_status = nullptr; ctx->h_costs = nullptr; ctx->tcap = 0;
+    drop_graphs(ctx);
+}
+
+static int ensure_tours(tspgpu_ctx *ctx, int want)
+{
+    if (want <= ctx->tcap) return E_OK;
+    want = std::max(want, 16); // growing re-allocates and invalidates every slot: start roomy
+    const int n = ctx->n;
+    if (ctx->tcap) {
+        // grow: keep it simple, slots are scratch between public calls
+        free_tours(ctx);
+    }
+    const size_t T = (size_t)want, N = (size_t)n;
+    Tours &S = ctx->S;
+    HIP_TRY(hipMalloc(&S.ord, T * N * 4));
+    HIP_TRY(hipMalloc(&S.pos, T * N * 4));
+    HIP_TRY(hipMalloc(&S.succ, T * N * 4));
+    HIP_TRY(hipMalloc(&S.dnext, T * N * 8));
+    HIP_TRY(hipMalloc(&S.cost, T * 8));
+    HIP_TRY(hipMalloc(&S.last_delta, T * 8));
+    HIP_TRY(hipMalloc(&S.done, T * 4));
+    HIP_TRY(hipMalloc(&S.nsweeps, T * 4));
+    HIP_TRY(hipMalloc(&S.cap_sweeps, T * 4));
+    HIP_TRY(hipMalloc(&S.status, T * 4));
+    HIP_TRY(hipMalloc(&S.partial, T * MAX_WGS_PER_TOUR * sizeof(Partial)));
+    HIP_TRY(hipMalloc(&ctx->d_starts, T * 4));
+    HIP_TRY(hipMalloc(&ctx->d_caps, T * 4));
+    HIP_TRY(hipMalloc(&ctx->d_tabu_list, N * 4));
+    HIP_TRY(hipMalloc(&ctx->d_best_succ, N * 4));
+    HIP_TRY(hipMalloc(&ctx->d_tabu, sizeof(TabuState)));
+    HIP_TRY(hipHostMalloc(&ctx->h_status, T * 4 * 2));
+    HIP_TRY(hipHostMalloc(&ctx->h_costs, T * 8));
+    HIP_TRY(hipMemsetAsync(S.done, 0, T * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.nsweeps, 0, T * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.status, 0, T * 4, ctx->stream));
+    ctx->tcap = want;
+    return E_OK;
+}
+
+static int new_instance(tspgpu_ctx *ctx, int n)
+{
+    if (n < 4) return fail(ctx, E_INVALID, "need at least 4 nodes, got %d", n);
+    if (n > 65535 * 64) return fail(ctx, E_INVALID, "n too large");
+    free_matrix(ctx);
+    free_tours(ctx);
+    ctx->n = n;
+    ctx->ld = (n + 31) & ~31; // rows 128-byte aligned for both element kinds
+    ctx->have_points = false;
+    ctx->symmetric = true;
+    return E_OK;
+}
+
+template <typename T> static const T *mat_of(const tspgpu_ctx *ctx);
+template <> const double *mat_of<double>(const tspgpu_ctx *ctx) { return ctx->d_f64; }
+template <> const int *mat_of<int>(const tspgpu_ctx *ctx) { return ctx->d_i32; }
+
+// --------------------------------------------------------------- launch plan
+template <typename T, int NCH, bool TABU> static const void *pipe_fn() { return (const void *)k_sweep_pipe<T, NCH, TABU>; }
+
+static const void *pipe_kernel(int elem, int nch, bool tabu)
+{
+#define PK(T, N) (tabu ? pipe_fn<T, N, true>() : pipe_fn<T, N, false>())
+    if (elem == TSPGPU_ELEM_F64) {
+        switch (nch) { case 1: return PK(double, 1); case 2: return PK(double, 2); case 4: return PK(double, 4); }
+    } else {
+        switch (nch) { case 1: return PK(int, 1); case 2: return PK(int, 2); case 4: return PK(int, 4); }
+    }
+#undef PK
+    return nullptr;
+}
+
+static const void *simple_kernel(int elem, bool tabu)
+{
+    if (elem == TSPGPU_ELEM_F64) return tabu ? (const void *)k_sweep_simple<double, true> : (const void *)k_sweep_simple<double, false>;
+    return tabu ? (const void *)k_sweep_simple<int, true> : (const void *)k_sweep_simple<int, false>;
+}
+
+static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// Decide kernel variant, block size, workgroups per tour for `ntours` tours in flight.
+static int make_plan(tspgpu_ctx *ctx, int ntours)
+{
+    const int n = ctx->n, ld = ctx->ld;
+    const size_t esz = ctx->elem == TSPGPU_ELEM_F64 ? 8 : 4;
+    const int V = 16 / (int)esz;
+    const int nvec = ld / V;
+    const size_t row = (size_t)ld * esz;
+    const size_t slack = 1024; // nodes[] + reduction scratch
+
+    int BT = ctx->opt_block;
+    if (BT <= 0) BT = std::min(1024, std::max(64, pow2_ceil((nvec + 1) / 2)));
+    BT = std::min(1024, std::max(64, (BT + 63) & ~63));
+
+    int kernel = ctx->opt_kernel;
+    int nch = 0;
+    auto pipe_fits = [&](int bt, int P) {
+        return 3 * row + (size_t)(P + 4) * 4 + slack <= ctx->lds_max;
+    };
+    // provisional G / P
+    auto plan_GP = [&](size_t lds, int bt, int &G, int &P) {
+        int occ = (int)std::min<size_t>(ctx->lds_max / std::max<size_t>(lds, 1), (size_t)(2048 / bt));
+        occ = std::max(1, std::min(occ, 8));
+        G = ctx->opt_wgs > 0 ? ctx->opt_wgs : std::max(1, (ctx->cus * occ + ntours - 1) / ntours);
+        G = std::min(G, MAX_WGS_PER_TOUR);
+        G = std::min(G, std::max(1, n / 2));
+        P = (n + G - 1) / G;
+        G = (n + P - 1) / P;
+    };
+    int G = 1, P = n;
+    if (kernel == 0) kernel = pipe_fits(BT, 64) ? 2 : 1;
+    if (kernel == 2) {
+        nch = (nvec + BT - 1) / BT;
+        while (nch > 4 && BT < 1024) { BT *= 2; nch = (nvec + BT - 1) / BT; }
+        int inst = nch <= 1 ? 1 : nch <= 2 ? 2 : 4;
+        if (nch > 4 || !pipe_fits(BT, 64)) {
+            if (ctx->opt_kernel == 2) return fail(ctx, E_EXHAUSTED, "pipelined sweep: 3 rows of %zu B do not fit %zu B of LDS", row, ctx->lds_max);
+            kernel = 1;
+        } else {
+            nch = inst;
+            plan_GP(3 * row + slack, BT, G, P);
+            if (ctx->opt_wgs <= 0 && P < 8) { // each run fetches P+1 rows: keep the extra row under ~12 %
+                P = std::min(n, 8); G = (n + P - 1) / P;
+            }
+            while (!pipe_fits(BT, P) && G < MAX_WGS_PER_TOUR) { G *= 2; P = (n + G - 1) / G; G = (n + P - 1) / P; }
+            ctx->plan_lds = 3 * row + (size_t)((P + 1 + 3) & ~3) * 4 + 16 * sizeof(Partial) + 64;
+        }
+    }
+    if (kernel == 1) {
+        if (row + slack > ctx->lds_max)
+            return fail(ctx, E_EXHAUSTED, "matrix mode needs one %zu-byte row in LDS (max %zu): n=%d too large", row, ctx->lds_max, n);
+        if (ctx->opt_block <= 0) BT = std::min(1024, std::max(64, pow2_ceil(nvec / 4)));
+        plan_GP(row + slack, BT, G, P);
+        ctx->plan_lds = row + 16 * sizeof(Partial) + 64;
+        nch = 0;
+    }
+    if (n > 64 * 1024) return fail(ctx, E_EXHAUSTED, "n=%d exceeds the matrix-mode limit", n);
+    ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
+    // raise the dynamic-LDS cap of the kernels we are going to launch
+    for (int tabu = 0; tabu < 2; tabu++) {
+        const void *fn = kernel == 2 ? pipe_kernel(ctx->elem, nch, tabu) : simple_kernel(ctx->elem, tabu);
+        if (!fn) return fail(ctx, E_INTERNAL, "no kernel instance for nch=%d", nch);
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
+    }
+    return E_OK;
+}
+
+static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
+{
+    SweepArgs A;
+    A.S = ctx->S;
+    A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
+    A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.P = ctx->plan_P;
+    A.symmetric = ctx->symmetric ? 1 : 0;
+    A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
+    const void *fn = ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, tabu) : simple_kernel(ctx->elem, tabu);
+    void *args[] = {&A};
+    HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
+    return E_OK;
+}
+
+static int launch_apply(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, bool resident_tabu)
+{
+    ApplyArgs A;
+    A.S = ctx->S;
+    A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
+    A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.G = ctx->plan_G;
+    A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
+    A.best_succ = ctx->d_best_succ; A.trace = resident_tabu ? ctx->d_trace : nullptr;
+    A.hist = ctx->hist;
+    const int BT = std::min(1024, std::max(64, pow2_ceil(ctx->n / 4)));
+    const void *fn;
+    if (ctx->elem == TSPGPU_ELEM_F64) fn = tabu ? (const void *)k_apply<double, true> : (const void *)k_apply<double, false>;
+    else fn = tabu ? (const void *)k_apply<int, true> : (const void *)k_apply<int, false>;
+    void *args[] = {&A};
+    HIP_TRY(hipLaunchKernel(fn, dim3(ntours), dim3(BT), args, 0, ctx->stream));
+    return E_OK;
+}
+
+static double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
+// done, `max_iters` pairs were issued (tabu), or the deadline passed.
+static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s,
+                      bool *deadline_hit)
+{
+    if (deadline_hit) *deadline_hit = false;
+    if (ctx->plan_T != ntours || ctx->plan_kernel == 0) {
+        int rc = make_plan(ctx, ntours);
+        if (rc) return rc;
+        drop_graphs(ctx);
+    }
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    const int K = std::max(1, ctx->opt_batch);
+    long issued = 0;
+    for (;;) {
+        int todo = K;
+        if (max_iters >= 0) todo = (int)std::min<long>(K, max_iters - issued);
+        if (todo <= 0) break;
+        const bool use_graph = ctx->opt_graph && !ctx->opt_timing && todo == K;
+        if (use_graph) {
+            hipGraphExec_t exec = nullptr;
+            for (auto &g : ctx->graphs)
+                if (g.slot0 == slot0 && g.ntours == ntours && g.tabu == (int)tabu && g.K == K) exec = g.exec;
+            if (!exec) {
+                hipGraph_t graph;
+                HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                int rc = E_OK;
+                for (int i = 0; i < K && !rc; i++) {
+                    rc = launch_sweep(ctx, slot0, ntours, tabu);
+                    if (!rc) rc = launch_apply(ctx, slot0, ntours, tabu, tabu);
+                }
+                hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                if (rc) return rc;
+                if (ce != hipSuccess) return fail(ctx, E_INTERNAL, "graph capture failed: %s", hipGetErrorString(ce));
+                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                hipGraphDestroy(graph);
+                ctx->graphs.push_back({slot0, ntours, (int)tabu, K, exec});
+            }
+            HIP_TRY(hipGraphLaunch(exec, ctx->stream));
+        } else {
+            if (ctx->opt_timing && (int)ctx->ev.size() < 2 * K) {
+                while ((int)ctx->ev.size() < 2 * K) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            }
+            for (int i = 0; i < todo; i++) {
+                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i], ctx->stream));
+                int rc = launch_sweep(ctx, slot0, ntours, tabu);
+                if (rc) return rc;
+                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i + 1], ctx->stream));
+                rc = launch_apply(ctx, slot0, ntours, tabu, tabu);
+                if (rc) return rc;
+            }
+        }
+        issued += todo;
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->opt_timing) {
+            // count only launches that did work: a finished tour's sweep exits at once
+            for (int i = 0; i < todo; i++) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+                ctx->sweep_ms_total += ms; ctx->sweep_launches++;
+            }
+        }
+        bool all = true;
+        for (int i = 0; i < ntours; i++) if (!ctx->h_status[i]) { all = false; break; }
+        if (all) break;
+        if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
+    }
+    return E_OK;
+}
+
+// host: successor array -> visiting order from node 0; validates the cycle
+static int succ_to_order(tspgpu_ctx *ctx, const int *path, std::vector<int> &ord)
+{
+    const int n = ctx->n;
+    ord.resize(n);
+    std::vector<unsigned char> seen(n, 0);
+    int v = 0;
+    for (int p = 0; p < n; p++) {
+        if (v < 0 || v >= n || seen[v]) return fail(ctx, E_INVALID, "path is not a single n-cycle");
+        seen[v] = 1; ord[p] = v; v = path[v];
+    }
+    if (v != 0) return fail(ctx, E_INVALID, "path is not a single n-cycle");
+    return E_OK;
+}
+
+static int init_slots(tspgpu_ctx *ctx, int slot0, int ntours, int cap)
+{
+    const int n = ctx->n;
+    int *caps = nullptr;
+    if (cap >= 0) {
+        std::vector<int> h(ntours, cap);
+        HIP_TRY(hipMemcpyAsync(ctx->d_caps, h.data(), (size_t)ntours * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream)); // h goes out of scope
+        caps = ctx->d_caps;
+    }
+    const int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
+    if (ctx->elem == TSPGPU_ELEM_F64)
+        hipLaunchKernelGGL((k_tour_init<double>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_f64, n, ctx->ld, slot0, caps);
+    else
+        hipLaunchKernelGGL((k_tour_init<int>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_i32, n, ctx->ld, slot0, caps);
+    HIP_TRY(hipGetLastError());
+    return E_OK;
+}
+
+static int need_costs(tspgpu_ctx *ctx)
+{
+    if (!ctx->have_costs) return fail(ctx, E_PRECOND, "no cost matrix: call tspgpu_build_costs or tspgpu_set_costs first");
+    return E_OK;
+}
+
+static int load_path(tspgpu_ctx *ctx, int slot, const int *path, int cap)
+{
+    std::vector<int> ord;
+    int rc = succ_to_order(ctx, path, ord);
+    if (rc) return rc;
+    rc = ensure_tours(ctx, std::max(slot + 1, 1));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->S.ord + (size_t)slot * ctx->n, ord.data(), (size_t)ctx->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return init_slots(ctx, slot, 1, cap);
+}
+
+static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
+{
+    const int n = ctx->n;
+    if (path) HIP_TRY(hipMemcpyAsync(path, ctx->S.succ + (size_t)slot * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (cost) HIP_TRY(hipMemcpyAsync(cost, ctx->S.cost + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (last_delta) HIP_TRY(hipMemcpyAsync(last_delta, ctx->S.last_delta + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return E_OK;
+}
+
+static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
+{
+    const int n = ctx->n;
+    for (int i = 0; i < count; i++)
+        if (h_starts[i] < 0 || h_starts[i] >= n) return fail(ctx, E_UNAVAILABLE, "starting node %d not in [0,%d)", h_starts[i], n);
+    HIP_TRY(hipMemcpyAsync(ctx->d_starts, h_starts, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
+    while ((long)BT * 64 < n) BT *= 2; // register visited mask: n <= 64*BT
+    if (BT > 1024) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 65536");
+    if (ctx->elem == TSPGPU_ELEM_F64)
+        hipLaunchKernelGGL((k_nn<double>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_f64, n, ctx->ld, slot0, ctx->d_starts);
+    else
+        hipLaunchKernelGGL((k_nn<int>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_i32, n, ctx->ld, slot0, ctx->d_starts);
+    HIP_TRY(hipGetLastError());
+    return E_OK;
+}
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+int tspgpu_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int tspgpu_create(int device, tspgpu_ctx **out)
+{
+    if (!out) return E_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return E_UNAVAILABLE;
+    if (device < 0 || device >= count) return E_INVALID;
+    tspgpu_ctx *ctx = new tspgpu_ctx();
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete ctx; return E_UNAVAILABLE; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return E_UNAVAILABLE; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // the code object is gfx950-only; say so instead of failing at first launch
+        fprintf(stderr, "tspgpu: device %d is %s, this library is built for gfx950\n", device, prop.gcnArchName);
+        delete ctx; return E_UNAVAILABLE;
+    }
+    ctx->cus = prop.multiProcessorCount;
+    int lds_optin = 0;
+    if (hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds_optin > 0)
+        ctx->lds_max = (size_t)lds_optin;
+    if (ctx->lds_max > 160 * 1024) ctx->lds_max = 160 * 1024;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return E_INTERNAL; }
+    if (hipMalloc(&ctx->d_flags, 64) != hipSuccess) { delete ctx; return E_INTERNAL; }
+    *out = ctx;
+    return E_OK;
+}
+
+void tspgpu_destroy(tspgpu_ctx *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    free_matrix(ctx);
+    free_tours(ctx);
+    if (ctx->d_pts) hipFree(ctx->d_pts);
+    if (ctx->d_flags) hipFree(ctx->d_flags);
+    if (ctx->d_trace) hipFree(ctx->d_trace);
+    if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); }
+    for (auto e : ctx->ev) hipEventDestroy(e);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *tspgpu_last_error(const tspgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
+{
+    if (!ctx) return E_INVALID;
+    hipSetDevice(ctx->device);
+    switch (option) {
+    case TSPGPU_OPT_ELEM: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad element kind"); ctx->opt_elem = (int)value; break;
+    case TSPGPU_OPT_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad kernel id"); ctx->opt_kernel = (int)value; ctx->plan_kernel = 0; break;
+    case TSPGPU_OPT_BATCH: if (value < 1 || value > 4096) return fail(ctx, E_INVALID, "bad batch"); ctx->opt_batch = (int)value; drop_graphs(ctx); break;
+    case TSPGPU_OPT_WGS_PER_TOUR: if (value < 0 || value > MAX_WGS_PER_TOUR) return fail(ctx, E_INVALID, "bad wgs"); ctx->opt_wgs = (int)value; ctx->plan_kernel = 0; break;
+    case TSPGPU_OPT_HISTORY: {
+        if (value < 0 || value > (1 << 22)) return fail(ctx, E_INVALID, "bad history size");
+        if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); ctx->hist = HistBuf{nullptr, nullptr, nullptr, 0}; }
+        if (value > 0) {
+            HIP_TRY(hipMalloc(&ctx->hist.a, value * 4));
+            HIP_TRY(hipMalloc(&ctx->hist.b, value * 4));
+            HIP_TRY(hipMalloc(&ctx->hist.d, value * 8));
+            ctx->hist.cap = (int)value;
+        }
+        ctx->opt_hist = (int)value; drop_graphs(ctx);
+        break;
+    }
+    case TSPGPU_OPT_GRAPH: ctx->opt_graph = value ? 1 : 0; break;
+    case TSPGPU_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; break;
+    case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
+    case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
+    default: return fail(ctx, E_INVALID, "unknown option %d", option);
+    }
+    return E_OK;
+}
+
+long tspgpu_info(const tspgpu_ctx *ctx, int what)
+{
+    if (!ctx) return -1;
+    switch (what) {
+    case 0: return ctx->n;
+    case 1: return ctx->ld;
+    case 2: return ctx->elem;
+    case 3: return ctx->plan_kernel;
+    case 4: return ctx->plan_G;
+    case 5: return (long)ctx->plan_lds;
+    case 6: return ctx->plan_BT;
+    case 7: return ctx->symmetric ? 1 : 0;
+    case 8: return ctx->cus;
+    }
+    return -1;
+}
+
+int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_type)
+{
+    if (!ctx || !xy) return fail(ctx, E_INVALID, "null argument");
+    if (edge_weight_type < 0 || edge_weight_type > 2) return fail(ctx, E_INVALID, "unknown edge weight type %d", edge_weight_type);
+    hipSetDevice(ctx->device);
+    int rc = new_instance(ctx, n);
+    if (rc) return rc;
+    if (ctx->d_pts) { hipFree(ctx->d_pts); ctx->d_pts = nullptr; }
+    HIP_TRY(hipMalloc(&ctx->d_pts, (size_t)n * sizeof(double2)));
+    HIP_TRY(hipMemcpy(ctx->d_pts, xy, (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
+    ctx->kind = edge_weight_type;
+    ctx->have_points = true;
+    return E_OK;
+}
+
+static int launch_build(tspgpu_ctx *ctx)
+{
+    const int n = ctx->n, ld = ctx->ld;
+    if (ctx->elem == TSPGPU_ELEM_F64) {
+        dim3 grid((ld / 2 + 255) / 256, n);
+        hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, ctx->d_f64);
+    } else {
+        dim3 grid((ld / 4 + 255) / 256, n);
+        hipLaunchKernelGGL((k_build_costs<int>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, ctx->d_i32);
+    }
+    HIP_TRY(hipGetLastError());
+    return E_OK;
+}
+
+int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
+{
+    if (!ctx) return E_INVALID;
+    hipSetDevice(ctx->device);
+    if (!ctx->have_points) return fail(ctx, E_PRECOND, "no points: call tspgpu_set_points first");
+    free_matrix(ctx);
+    const size_t cells = (size_t)ctx->n * ctx->ld;
+    // every supported edge-weight kind yields integers, so AUTO means int32
+    ctx->elem = ctx->opt_elem == TSPGPU_ELEM_F64 ? TSPGPU_ELEM_F64 : TSPGPU_ELEM_I32;
+    if (ctx->elem == TSPGPU_ELEM_F64) HIP_TRY(hipMalloc(&ctx->d_f64, cells * 8));
+    else HIP_TRY(hipMalloc(&ctx->d_i32, cells * 4));
+    int rc = launch_build(ctx);
+    if (rc) return rc;
+    ctx->symmetric = true; // Euclidean
+    ctx->have_costs = true;
+    ctx->plan_kernel = 0;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (host_out) return tspgpu_get_costs(ctx, host_out);
+    return E_OK;
+}
+
+int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
+{
+    if (!ctx || !host_costs) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    if (n != ctx->n || !ctx->n) {
+        int rc = new_instance(ctx, n);
+        if (rc) return rc;
+    } else {
+        free_matrix(ctx);
+    }
+    const int ld = ctx->ld;
+    const size_t cells = (size_t)n * ld;
+    HIP_TRY(hipMalloc(&ctx->d_f64, cells * 8));
+    HIP_TRY(hipMemsetAsync(ctx->d_f64, 0, cells * 8, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(ctx->d_f64, (size_t)ld * 8, host_costs, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_inspect, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_f64, n, ld, ctx->d_flags);
+    HIP_TRY(hipGetLastError());
+    int flags[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const bool integral = flags[0] == 0;
+    ctx->symmetric = flags[1] == 0;
+    if (ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) {
+        free_matrix(ctx);
+        return fail(ctx, E_INVALID, "int32 storage requested but the matrix is not integer-valued in [-1, 2^28)");
+    }
+    ctx->elem = (ctx->opt_elem == TSPGPU_ELEM_F64 || !integral) ? TSPGPU_ELEM_F64 : TSPGPU_ELEM_I32;
+    if (ctx->elem == TSPGPU_ELEM_I32) {
+        HIP_TRY(hipMalloc(&ctx->d_i32, cells * 4));
+        hipLaunchKernelGGL(k_f64_to_i32, dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_f64, n, ld, ctx->d_i32);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        hipFree(ctx->d_f64); ctx->d_f64 = nullptr;
+    }
+    ctx->have_costs = true;
+    ctx->plan_kernel = 0;
+    return E_OK;
+}
+
+int tspgpu_get_costs(tspgpu_ctx *ctx, double *host_out)
+{
+    if (!ctx || !host_out) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    const int n = ctx->n, ld = ctx->ld;
+    const double *src = ctx->d_f64;
+    double *tmp = nullptr;
+    if (ctx->elem == TSPGPU_ELEM_I32) {
+        HIP_TRY(hipMalloc(&tmp, (size_t)n * ld * 8));
+        hipLaunchKernelGGL(k_i32_to_f64, dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_i32, n, ld, tmp);
+        src = tmp;
+    }
+    hipError_t e = hipMemcpy2DAsync(host_out, (size_t)n * 8, src, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (tmp) hipFree(tmp);
+    if (e != hipSuccess) return fail(ctx, E_INTERNAL, "matrix download: %s", hipGetErrorString(e));
+    return E_OK;
+}
+
+int tspgpu_nn_tour(tspgpu_ctx *ctx, int start, int *path, double *cost)
+{
+    if (!ctx || !path || !cost) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if (start < 0 || start >= ctx->n) return fail(ctx, E_UNAVAILABLE, "starting node not correct"); // heuristics.c:223-226
+    if ((rc = ensure_tours(ctx, 1))) return rc;
+    if ((rc = launch_nn(ctx, 0, &start, 1))) return rc;
+    double nn_cost = 0;
+    HIP_TRY(hipMemcpyAsync(&nn_cost, ctx->S.cost, 8, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = init_slots(ctx, 0, 1, -1))) return rc; // derives succ[]
+    if ((rc = store_path(ctx, 0, path, nullptr, nullptr))) return rc;
+    *cost = nn_cost; // the running sum of heuristics.c:276,281, not the node-order recompute
+    return E_OK;
+}
+
+int tspgpu_tour_load(tspgpu_ctx *ctx, int slot, const int *path)
+{
+    if (!ctx || !path || slot < 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    return load_path(ctx, slot, path, -1);
+}
+
+int tspgpu_tour_nn(tspgpu_ctx *ctx, int slot, int start)
+{
+    if (!ctx || slot < 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if ((rc = ensure_tours(ctx, slot + 1))) return rc;
+    if ((rc = launch_nn(ctx, slot, &start, 1))) return rc;
+    return init_slots(ctx, slot, 1, -1);
+}
+
+int tspgpu_tour_copy(tspgpu_ctx *ctx, int dst, int src)
+{
+    if (!ctx || dst < 0 || src < 0 || src >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    hipSetDevice(ctx->device);
+    if (dst >= ctx->tcap) return fail(ctx, E_INVALID, "destination slot %d not allocated (capacity %d)", dst, ctx->tcap);
+    hipLaunchKernelGGL(k_copy_tour, dim3(std::max(1, ctx->n / 256)), dim3(256), 0, ctx->stream, ctx->S, ctx->n, dst, src);
+    HIP_TRY(hipGetLastError());
+    return E_OK;
+}
+
+int tspgpu_tour_two_opt(tspgpu_ctx *ctx, int slot, long max_sweeps, double time_left_s, long *sweeps)
+{
+    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, ctx->stream, ctx->S, slot, 1, (int)std::min<long>(max_sweeps, INT_MAX));
+    HIP_TRY(hipGetLastError());
+    bool late = false;
+    if ((rc = run_sweeps(ctx, slot, 1, false, -1, time_left_s, &late))) return rc;
+    if (sweeps) {
+        int ns = 0;
+        HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps + slot, 4, hipMemcpyDeviceToHost));
+        *sweeps = ns;
+    }
+    return late ? E_DEADLINE : E_OK;
+}
+
+int tspgpu_tour_store(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
+{
+    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    hipSetDevice(ctx->device);
+    return store_path(ctx, slot, path, cost, last_delta);
+}
+
+int tspgpu_two_opt_once(tspgpu_ctx *ctx, int *path, double *cost, double *delta)
+{
+    if (!ctx || !path || !cost) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if ((rc = load_path(ctx, 0, path, 1))) return rc;
+    // ref_2opt_once trusts the caller's running cost (refinment.c:83): keep it
+    HIP_TRY(hipMemcpyAsync(ctx->S.cost, cost, 8, hipMemcpyHostToDevice, ctx->stream));
+    const int save_graph = ctx->opt_graph;
+    ctx->opt_graph = 0;
+    rc = run_sweeps(ctx, 0, 1, false, 1, -1, nullptr);
+    ctx->opt_graph = save_graph;
+    if (rc) return rc;
+    double d = 0;
+    if ((rc = store_path(ctx, 0, path, cost, &d))) return rc;
+    if (delta) *delta = d;
+    return E_OK;
+}
+
+int tspgpu_two_opt(tspgpu_ctx *ctx, int *path, double *cost, double time_left_s, long *sweeps)
+{
+    if (!ctx || !path || !cost) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if ((rc = load_path(ctx, 0, path, -1))) return rc;
+    bool late = false;
+    if ((rc = run_sweeps(ctx, 0, 1, false, -1, time_left_s, &late))) return rc;
+    if (sweeps) {
+        int ns = 0;
+        HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost));
+        *sweeps = ns;
+    }
+    if ((rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
+    return late ? E_DEADLINE : E_OK;
+}
+
+static int tabu_prepare(tspgpu_ctx *ctx, const int *tabu_list, int tenure, int iter, int t_min, int t_max, int up,
+                        int resident, double best_cost)
+{
+    TabuState ts;
+    ts.iter = iter; ts.tenure = tenure; ts.t_min = t_min; ts.t_max = t_max; ts.up = up; ts.resident = resident;
+    ts.best_cost = best_cost;
+    HIP_TRY(hipMemcpyAsync(ctx->d_tabu, &ts, sizeof ts, hipMemcpyHostToDevice, ctx->stream));
+    if (tabu_list) HIP_TRY(hipMemcpyAsync(ctx->d_tabu_list, tabu_list, (size_t)ctx->n * 4, hipMemcpyHostToDevice, ctx->stream));
+    else HIP_TRY(hipMemsetAsync(ctx->d_tabu_list, 0xff, (size_t)ctx->n * 4, ctx->stream)); // all -1
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return E_OK;
+}
+
+int tspgpu_tabu_move(tspgpu_ctx *ctx, int *path, double *cost, int *tabu_list, int tenure, int iter)
+{
+    if (!ctx || !path || !cost || !tabu_list) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if ((rc = load_path(ctx, 0, path, 1))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->S.cost, cost, 8, hipMemcpyHostToDevice, ctx->stream)); // running cost, metaheuristic.c:233
+    if ((rc = tabu_prepare(ctx, tabu_list, tenure, iter, INT_MIN, INT_MAX, 1, 0, 0.0))) return rc;
+    const int save_graph = ctx->opt_graph;
+    ctx->opt_graph = 0;
+    rc = run_sweeps(ctx, 0, 1, true, 1, -1, nullptr);
+    ctx->opt_graph = save_graph;
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(tabu_list, ctx->d_tabu_list, (size_t)ctx->n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    return store_path(ctx, 0, path, cost, nullptr);
+}
+
+int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *best_path, double *best_cost, double *trace)
+{
+    if (!ctx || !path || !cost || !best_path || !best_cost || k < 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    const int n = ctx->n;
+    if ((rc = load_path(ctx, 0, path, k))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->S.cost, cost, 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(ctx->d_best_succ, path, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (k > ctx->trace_cap) {
+        if (ctx->d_trace) hipFree(ctx->d_trace);
+        ctx->d_trace = nullptr; ctx->trace_cap = 0;
+        HIP_TRY(hipMalloc(&ctx->d_trace, (size_t)k * 8));
+        ctx->trace_cap = k;
+        drop_graphs(ctx);
+    }
+    // tabu_init (metaheuristic.c:65-84) then the first policy step (:126-143 -> :40-59)
+    int tenure = (int)(0.125 * n + 1), t_max = (int)(0.25 * n), t_min = (int)(0.125 * n), up = 1;
+    if (tenure == t_max || tenure == t_min) up = !up;
+    tenure += up ? 1 : -1;
+    if ((rc = tabu_prepare(ctx, nullptr, tenure, 0, t_min, t_max, up, 1, *cost))) return rc;
+    if (k > 0 && (rc = run_sweeps(ctx, 0, 1, true, k, -1, nullptr))) return rc;
+    if (trace && k > 0) HIP_TRY(hipMemcpyAsync(trace, ctx->d_trace, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
+    TabuState ts;
+    HIP_TRY(hipMemcpyAsync(&ts, ctx->d_tabu, sizeof ts, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(best_path, ctx->d_best_succ, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
+    *best_cost = ts.best_cost;
+    return E_OK;
+}
+
+int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts, int *best_path, double *best_cost, int *best_start)
+{
+    if (!ctx || !best_path || !best_cost || !best_start || nstarts <= 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    const int n = ctx->n;
+    const int chunk = std::min(nstarts, ctx->opt_max_tours);
+    if ((rc = ensure_tours(ctx, chunk))) return rc;
+    double best = DBL_MAX; int arg = -1;
+    std::vector<int> hs(chunk);
+    for (int base = 0; base < nstarts; base += chunk) {
+        const int m = std::min(chunk, nstarts - base);
+        for (int i = 0; i < m; i++) hs[i] = starts ? starts[base + i] : base + i;
+        if ((rc = launch_nn(ctx, 0, hs.data(), m))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_costs, ctx->S.cost, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int win = -1;
+        for (int i = 0; i < m; i++) if (ctx->h_costs[i] < best) { best = ctx->h_costs[i]; win = i; } // strict <, heuristics.c:58
+        if (win >= 0) {
+            arg = hs[win];
+            if ((rc = init_slots(ctx, win, 1, -1))) return rc;
+            if ((rc = store_path(ctx, win, best_path, nullptr, nullptr))) return rc;
+        }
+    }
+    *best_cost = best; *best_start = arg;
+    return E_OK;
+}
+
+int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, double time_left_s, int *best_path,
+                              double *best_cost, int *best_start, long *total_sweeps, int *last_path, double *last_cost)
+{
+    if (!ctx || !best_path || !best_cost || !best_start || nstarts <= 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    const int n = ctx->n;
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    const int chunk = std::min(nstarts, ctx->opt_max_tours);
+    if ((rc = ensure_tours(ctx, chunk))) return rc;
+    double best = DBL_MAX; int arg = -1; long sweeps = 0;
+    bool late = false;
+    std::vector<int> hs(chunk);
+    for (int base = 0; base < nstarts && !late; base += chunk) {
+        const int m = std::min(chunk, nstarts - base);
+        for (int i = 0; i < m; i++) hs[i] = starts ? starts[base + i] : base + i;
+        if ((rc = launch_nn(ctx, 0, hs.data(), m))) return rc;
+        if ((rc = init_slots(ctx, 0, m, -1))) return rc;
+        const double left = t_end >= 0 ? std::max(0.0, t_end - now_s()) : -1;
+        if ((rc = run_sweeps(ctx, 0, m, false, -1, left, &late))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_costs, ctx->S.cost, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.nsweeps, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        int win = -1;
+        for (int i = 0; i < m; i++) {
+            sweeps += ctx->h_status[i];
+            if (ctx->h_costs[i] < best) { best = ctx->h_costs[i]; win = i; } // strict <, tsp.c:671
+        }
+        if (win >= 0) {
+            arg = hs[win];
+            if ((rc = store_path(ctx, win, best_path, nullptr, nullptr))) return rc;
+        }
+        if (base + m >= nstarts && last_path) {
+            if ((rc = store_path(ctx, m - 1, last_path, last_cost, nullptr))) return rc;
+        }
+    }
+    *best_cost = best; *best_start = arg;
+    if (total_sweeps) *total_sweeps = sweeps;
+    return late ? E_DEADLINE : E_OK;
+}
+
+int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean)
+{
+    if (!ctx || !ms_mean || reps <= 0 || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, ctx->stream, ctx->S, slot, 1, -1);
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    if ((rc = launch_sweep(ctx, slot, 1, false))) return rc; // warm
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; i++) if ((rc = launch_sweep(ctx, slot, 1, false))) return rc;
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_mean = ms / reps;
+    return E_OK;
+}
+
+int tspgpu_time_build(tspgpu_ctx *ctx, int reps, float *ms_mean)
+{
+    if (!ctx || !ms_mean || reps <= 0) return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if (!ctx->have_points) return fail(ctx, E_PRECOND, "no points");
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    if ((rc = launch_build(ctx))) return rc;
+    HIP_TRY(hipEventRecord(e0, ctx->stream));
+    for (int i = 0; i < reps; i++) if ((rc = launch_build(ctx))) return rc;
+    HIP_TRY(hipEventRecord(e1, ctx->stream));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    *ms_mean = ms / reps;
+    return E_OK;
+}
+
+int tspgpu_timing_read(tspgpu_ctx *ctx, double *sweep_ms_total, long *sweep_launches, int reset)
+{
+    if (!ctx) return E_INVALID;
+    if (sweep_ms_total) *sweep_ms_total = ctx->sweep_ms_total;
+    if (sweep_launches) *sweep_launches = ctx->sweep_launches;
+    if (reset) { ctx->sweep_ms_total = 0; ctx->sweep_launches = 0; }
+    return E_OK;
+}
+
+int tspgpu_history(tspgpu_ctx *ctx, int *a, int *b, double *delta, int capacity, int *count)
+{
+    if (!ctx || !count) return fail(ctx, E_INVALID, "null argument");
+    hipSetDevice(ctx->device);
+    int ns = 0;
+    if (ctx->tcap > 0) HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost));
+    int m = std::min(std::min(ns, ctx->hist.cap), capacity);
+    if (m > 0) {
+        if (a) HIP_TRY(hipMemcpy(a, ctx->hist.a, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (b) HIP_TRY(hipMemcpy(b, ctx->hist.b, (size_t)m * 4, hipMemcpyDeviceToHost));
+        if (delta) HIP_TRY(hipMemcpy(delta, ctx->hist.d, (size_t)m * 8, hipMemcpyDeviceToHost));
+    }
+    *count = m;
+    return E_OK;
+}
+
+} // extern "C"
