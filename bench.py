@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: 2-opt delta evaluations per second and wall-clock to the
+2-opt local optimum on the n=4096 uniform-random EUC_2D instance (BASELINE.json `metric`).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One STEP = one full best-improvement 2-opt local search on the device: the nearest-
+neighbour tour (already resident in HBM, next to the cost matrix) is copied into a work
+slot and swept to its local optimum -- hundreds of (sweep, apply-move) launch pairs,
+exactly the trajectory of the reference's ref_2opt (src/algorithms/refinment.c:3-37).
+Matrix build and NN construction are outside the timed region, as in the reference
+(src/main.c:177 starts the clock after tsp_compute_costs) and SURVEY 8(d).
+
+  value        = valid pair evaluations per second, whole job: sum over ranks of
+                 sweeps * n(n-3)/2, divided by the max-over-ranks wall time
+  ms_per_step  = wall-clock of one NN(start) -> local optimum search (per rank)
+  N > 1        = weak scaling: rank r searches from NN start r (the multi-start loop of
+                 h_greedy_2opt, heuristics.c:82-111, sharded), then ONE RCCL MIN
+                 all-reduce picks the best tour and its owner broadcasts it (4n bytes).
+
+Extra objects on the JSON line: "roofline" (dominant kernel = the sweep kernel; achieved =
+algorithmic bytes per launch / mean kernel duration from HIP events on the engine's
+stream) and "cpu_baseline" (the reference's own CPU 2-opt on this box's host, 1 core,
+bounded sample).  Nothing here reads /root/reference.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
+
+
+def reference_points(n, seed):
+    """src/tsp.c:468-476 + utils.h:23-26 on glibc: srand(seed); x,y = rand()/RAND_MAX*10000-5000.
+    Re-stated here (4 lines of libc calls) so that the product bench does not import the oracle."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.srand(ctypes.c_uint(seed))
+    RAND_MAX = 2147483647
+    xy = np.empty((n, 2), dtype=np.float64)
+    for i in range(n):
+        xy[i, 0] = (libc.rand() / RAND_MAX) * 10000 + (-5000)
+        xy[i, 1] = (libc.rand() / RAND_MAX) * 10000 + (-5000)
+    return xy
+
+
+def cpu_baseline(n, seed, sample_sweeps):
+    """The reference's CPU 2-opt on this host, one core (the reference is single-threaded).
+    kind "reference": oracle/_ref/libtspref.so = the reference's own sources compiled in the
+    authoring container; kind "port": oracle/cpu_ref.c (bit-identical restatement)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    evals = n * (n - 3) // 2
+    try:
+        ref = O.Reference()
+        ref.random(n, seed)
+        succ, _, _ = ref.nn(0)
+        t0 = time.perf_counter()
+        sweeps, cost, _ = ref.two_opt_counted(succ, sample_sweeps)
+        dt = time.perf_counter() - t0
+        kind = "reference"
+    except (FileNotFoundError, OSError):
+        xy = O.random_points(n, seed)
+        c = O.cost_matrix(xy)
+        succ, _ = O.nn_tour(c, 0)
+        t0 = time.perf_counter()
+        sweeps, cost = O.two_opt(c, succ, sample_sweeps)
+        dt = time.perf_counter() - t0
+        kind = "port"
+    return {"value": sweeps * evals / dt, "unit": "evals/s", "cores": 1, "kind": kind,
+            "sample": f"first {sweeps} of the sweeps of the same n={n} seed={seed} NN(0) local search, "
+                      f"{dt:.1f} s, f64 matrix, gcc -O3",
+            "ms_per_sweep": 1e3 * dt / sweeps, "host_cores_available": os.cpu_count()}
+
+
+def load_traffic(workload_key):
+    """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/), or None."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(p):
+        try:
+            return json.load(open(p)).get(workload_key)
+        except Exception:
+            return None
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--seed", type=int, default=123)
+    ap.add_argument("--elem", choices=["i32", "f64"], default=os.environ.get("TSPGPU_BENCH_ELEM", "i32"))
+    ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--wgs", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--cpu-sweeps", type=int, default=150, help="bounded CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import travellingsalesmanoptimization_amd as T
+    from travellingsalesmanoptimization_amd import multistart
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+
+    n, seed = args.n, args.seed
+    evals = T.evals_per_sweep(n)
+    eng = T.Engine(local)
+    eng.set_option(T.OPT_ELEM, T.ELEM_I32 if args.elem == "i32" else T.ELEM_F64)
+    eng.set_option(T.OPT_KERNEL, args.kernel)
+    eng.set_option(T.OPT_WGS_PER_TOUR, args.wgs)
+    eng.set_option(T.OPT_BLOCK, args.block)
+    eng.set_option(T.OPT_BATCH, args.batch)
+
+    # ---- untimed setup: instance, matrix build on the device, NN seed tour in slot 0
+    xy = reference_points(n, seed)
+    eng.set_points(xy)
+    eng.build_costs()
+    build_ms = eng.time_build(5)
+    start = rank % n                       # rank r = the r-th iteration of h_greedy_2opt's loop
+    t0 = time.perf_counter()
+    eng.tour_nn(0, start)
+    _, nn_cost, _ = eng.tour_store(0, want_path=False)
+    nn_ms = 1e3 * (time.perf_counter() - t0)
+    eng.tour_copy(1, 0)
+
+    def step():
+        eng.tour_copy(1, 0)                 # restore the NN tour (device to device)
+        sweeps, _ = eng.tour_two_opt(1)     # sweep to the local optimum, resident
+        return sweeps
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    my_sweeps = 0
+    for _ in range(args.steps):
+        my_sweeps += step()
+        if world > 1:
+            # the exchange step of the sharded multi-start: one MIN all-reduce + winner broadcast
+            path, cost, _ = eng.tour_store(1)
+            multistart.select_best(cost, start, path, device=dev)
+    sync_all()
+    dt = time.perf_counter() - t0
+    path, final_cost, _ = eng.tour_store(1)
+
+    tot_sweeps, tmax = my_sweeps, dt
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        s = torch.tensor([my_sweeps], dtype=torch.int64, device=dev)
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        tmax, tot_sweeps = float(t.item()), int(s.item())
+
+    # ---- roofline of the dominant kernel: same search once more, every sweep launch bracketed
+    # by HIP events on the engine's stream (eager launches; the timed region above replays graphs)
+    roof = None
+    if rank == 0:
+        eng.set_option(T.OPT_TIMING, 1)
+        eng.timing_read(reset=True)
+        eng.tour_copy(1, 0)
+        eng.tour_two_opt(1)
+        ms_total, launches = eng.timing_read(reset=True)
+        eng.set_option(T.OPT_TIMING, 0)
+        info = eng.info()
+        bytes_per_eval = 8 if info["elem"] == T.ELEM_I32 else 16   # 2 matrix elements per eval
+        kernel_ms = ms_total / max(launches, 1)
+        achieved = evals * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
+        back2back_ms = eng.time_sweep(1, 50)                         # 50 launches, no apply in between
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": load_traffic(f"n{n}_{args.elem}"),
+                "kernel": {1: "k_sweep_simple", 2: "k_sweep_pipe"}[info["kernel"]],
+                "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
+                "kernel_ms_back_to_back": back2back_ms,
+                "algorithmic_bytes_per_launch": evals * bytes_per_eval,
+                "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals,
+                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
+
+    base = None
+    if rank == 0 and world == 1 and args.cpu_sweeps > 0:
+        base = cpu_baseline(n, seed, args.cpu_sweeps)
+
+    if rank == 0:
+        info = eng.info()
+        out = {
+            "metric": "2-opt delta evals/sec/node (n=4096 EUC_2D, NN(0) tour to 2-opt local optimum)",
+            "value": tot_sweeps * evals / tmax,
+            "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * tmax / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32" if info["elem"] == T.ELEM_I32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": f"uniform-random EUC_2D n={n} (reference generator -n {n} -seed {seed}), "
+                                   f"cost matrix resident in HBM, NN(start=rank) tour -> best-improvement 2-opt "
+                                   f"to the local optimum; one step = one full local search",
+                       "n": n, "seed": seed, "evals_per_sweep": evals,
+                       "sweeps_per_step_rank0": my_sweeps // max(args.steps, 1),
+                       "matrix_elem": "int32 exact copy" if info["elem"] == T.ELEM_I32 else "f64",
+                       "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
+                       "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
+                       "parallelism": f"multistart-shard{world}"},
+            "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
+            "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost,
+            "matrix_build_ms": build_ms, "nn_tour_ms": nn_ms,
+            "roofline": roof, "cpu_baseline": base,
+        }
+        if base:
+            out["gpu_over_cpu"] = out["value"] / base["value"]
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -241,8 +241,8 @@ class Reference:
         L.refdrv_mod_costs.argtypes = [_dp, _ip, C.POINTER(C.c_double)]
         L.refdrv_run.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), _ip, C.POINTER(C.c_int)]
         self.L = L
-        scratch = scratch or os.path.join(HERE, "_ref", "scratch")
-        if L.refdrv_init(scratch.encode()):
+        self.scratch = scratch or os.path.join(HERE, "_ref", "scratch")
+        if L.refdrv_init(self.scratch.encode()):
             raise OSError("refdrv_init failed")
 
     @property
@@ -311,5 +311,10 @@ class Reference:
     def run(self, alg, k=2147483647):
         succ = np.zeros(self.n, dtype=np.int32)
         c, s = C.c_double(), C.c_int()
-        rc = self.L.refdrv_run(alg, k, C.byref(c), succ, C.byref(s))
+        cwd = os.getcwd()
+        os.chdir(self.scratch)  # the reference writes results/*.dat relative to the cwd
+        try:
+            rc = self.L.refdrv_run(alg, k, C.byref(c), succ, C.byref(s))
+        finally:
+            os.chdir(cwd)
         return succ, c.value, s.value, rc

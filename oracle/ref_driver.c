@@ -38,10 +38,13 @@ int refdrv_init(const char *scratch_dir)
 {
     signal(SIGPIPE, SIG_IGN);
     if (scratch_dir && *scratch_dir) {
+        /* mh_TabuSearch / mh_VNS fopen("results/...") relative to the cwd
+         * (metaheuristic.c:97,275): the Python wrapper chdirs here around them */
+        char buf[4096];
         mkdir(scratch_dir, 0777);
-        if (chdir(scratch_dir) != 0) return -1;
+        snprintf(buf, sizeof buf, "%s/results", scratch_dir);
+        mkdir(buf, 0777);
     }
-    mkdir("results", 0777);   /* metaheuristic.c:97,275 fopen("results/...") */
     drop_instance();
     tsp_init();
     err_setverbosity(QUIET);

@@ -1,0 +1,99 @@
+"""The N>1 path on CPU: world_size-2 `gloo` run of the sharded multi-start driver
+(travellingsalesmanoptimization_amd/multistart.py).  The per-rank solver is injected; here
+it is the oracle (test infrastructure), on the GPU box it is Engine.multistart_nn_2opt."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, name, float_costs, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    from travellingsalesmanoptimization_amd import multistart
+    xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", name + ".tsp"))
+    c = O.cost_matrix(xy)
+    if float_costs:
+        c = np.ascontiguousarray(c * 0.731)
+    n = len(xy)
+
+    def solve_local(starts):
+        path, cost, start, sweeps = O.multistart_nn_2opt(c, starts)
+        return {"path": path, "cost": cost, "start": start, "sweeps": sweeps}
+
+    starts = np.arange(n, dtype=np.int32) if not float_costs else np.arange(0, n, 3, dtype=np.int32)
+    res = multistart.multistart_nn_2opt(solve_local, starts)
+    q.put((rank, res["cost"], res["start"], res["sweeps"], O.fnv1a(res["path"])))
+    dist.destroy_process_group()
+
+
+def _run(world, name, float_costs=False):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, float_costs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    return sorted(out)
+
+
+@pytest.mark.parametrize("name", ["berlin52", "kroA100"])
+def test_two_ranks_equal_sequential_golden(golden, name):
+    """sharding start i -> rank i mod 2 and one MIN all-reduce gives the sequential
+    h_greedy_2opt result (golden, from the reference) on every rank"""
+    g = golden["algs"][name + "_2opt_greedy"]
+    out = _run(2, name)
+    assert len(out) == 2
+    for rank, cost, start, sweeps, fnv in out:
+        assert cost == g["cost"] and f"{fnv:016x}" == g["fnv"]
+    assert out[0][1:] == out[1][1:]
+
+
+def test_three_ranks_float_costs_allgather_path(O):
+    """non-integer costs cannot be packed into the int64 key: all-gather fallback"""
+    out = _run(3, "berlin52", float_costs=True)
+    xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", "berlin52.tsp"))
+    c = np.ascontiguousarray(O.cost_matrix(xy) * 0.731)
+    want = O.multistart_nn_2opt(c, np.arange(0, 52, 3, dtype=np.int32))
+    for rank, cost, start, sweeps, fnv in out:
+        assert (cost, start, sweeps, fnv) == (want[1], want[2], want[3], O.fnv1a(want[0]))
+
+
+def test_pack_key_and_sharding():
+    sys.path.insert(0, ROOT)
+    from travellingsalesmanoptimization_amd import multistart as M
+    assert M.pack_key(266290.0, 1001) == (266290 << 32) | 1001
+    assert M.pack_key(1121.03, 5) is None
+    # lowest cost wins; ties go to the lowest start id (the strict < of tsp.c:671 under
+    # ascending iteration order)
+    keys = [M.pack_key(7657.0, 51), M.pack_key(7657.0, 12), M.pack_key(7700.0, 0)]
+    assert min(keys) == M.pack_key(7657.0, 12)
+    s = np.arange(10)
+    assert M.shard_starts(s, 1, 4).tolist() == [1, 5, 9]
+    assert sum(len(M.shard_starts(s, r, 4)) for r in range(4)) == 10
+    # single process: no collective is issued
+    c, st, p = M.select_best(5.0, 3, np.arange(4, dtype=np.int32))
+    assert (c, st) == (5.0, 3)

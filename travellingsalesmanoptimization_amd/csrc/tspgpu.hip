@@ -1051,17 +1051,21 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
                 if (rc) return rc;
             }
         }
-        issued += todo;
         HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->opt_timing)
+            HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (ctx->opt_timing) {
-            // count only launches that did work: a finished tour's sweep exits at once
-            for (int i = 0; i < todo; i++) {
+            // count only launches that did work: once every tour is done a sweep exits at once
+            int live = 0;
+            for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
+            for (int i = 0; i < todo && issued + i < live; i++) {
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
                 ctx->sweep_ms_total += ms; ctx->sweep_launches++;
             }
         }
+        issued += todo;
         bool all = true;
         for (int i = 0; i < ntours; i++) if (!ctx->h_status[i]) { all = false; break; }
         if (all) break;
@@ -1180,10 +1184,9 @@ int tspgpu_create(int device, tspgpu_ctx **out)
         delete ctx; return E_UNAVAILABLE;
     }
     ctx->cus = prop.multiProcessorCount;
-    int lds_optin = 0;
-    if (hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && lds_optin > 0)
-        ctx->lds_max = (size_t)lds_optin;
-    if (ctx->lds_max > 160 * 1024) ctx->lds_max = 160 * 1024;
+    // gfx950: 160 KiB of LDS per CU, and one workgroup may take all of it
+    // (MI355X_MICROARCH.md, register files / LDS); the generic attribute still says 64 KiB.
+    ctx->lds_max = 160 * 1024;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return E_INTERNAL; }
     if (hipMalloc(&ctx->d_flags, 64) != hipSuccess) { delete ctx; return E_INTERNAL; }
     *out = ctx;
