@@ -38,7 +38,7 @@ typedef struct tspgpu_ctx tspgpu_ctx;
 enum { TSPGPU_EUC_2D = 0, TSPGPU_ATT = 1, TSPGPU_CEIL_2D = 2 };
 
 /* storage of the device-resident cost matrix.  AUTO keeps an exact int32 copy
- * when every entry is an integer in [-1, 2^28) (true for every EUC_2D / ATT /
+ * when every entry is an integer in [-1, 2^27) (true for every EUC_2D / ATT /
  * CEIL_2D matrix), else doubles. */
 enum { TSPGPU_ELEM_AUTO = 0, TSPGPU_ELEM_F64 = 1, TSPGPU_ELEM_I32 = 2 };
 
@@ -52,7 +52,8 @@ enum {
     TSPGPU_OPT_GRAPH = 6,       /* 1 = replay sweep batches as a hipGraph (default 1) */
     TSPGPU_OPT_TIMING = 7,      /* 1 = bracket every sweep kernel with HIP events */
     TSPGPU_OPT_BLOCK = 8,       /* threads per sweep workgroup (0 = auto) */
-    TSPGPU_OPT_MAX_TOURS = 9    /* tours kept in flight by the multi-start driver */
+    TSPGPU_OPT_MAX_TOURS = 9,   /* tours kept in flight by the multi-start driver */
+    TSPGPU_OPT_DEPTH = 10       /* matrix rows in flight per workgroup in the pipelined sweep (0 = auto) */
 };
 
 int  tspgpu_device_count(void);
@@ -62,7 +63,7 @@ const char *tspgpu_last_error(const tspgpu_ctx *ctx);
 int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
 /* info: 0 n, 1 row stride, 2 element kind in use, 3 sweep kernel in use,
  * 4 workgroups per tour, 5 LDS bytes per workgroup, 6 threads per workgroup,
- * 7 matrix is symmetric, 8 compute units */
+ * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */
@@ -149,6 +150,9 @@ int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean);
 int tspgpu_time_build(tspgpu_ctx *ctx, int reps, float *ms_mean);
 /* with TSPGPU_OPT_TIMING: sum of sweep-kernel ms and launch count since reset */
 int tspgpu_timing_read(tspgpu_ctx *ctx, double *sweep_ms_total, long *sweep_launches, int reset);
+/* diagnostics: 64 wall-clock stamps (10 ns ticks) per sweep workgroup of the last launch
+ * made while stamping was enabled (tools/stamps.py); not part of the reference's surface */
+int tspgpu_debug_stamps(tspgpu_ctx *ctx, unsigned long long *out, int capacity_words);
 /* with TSPGPU_OPT_HISTORY: the recorded moves of slot 0; returns count in *count */
 int tspgpu_history(tspgpu_ctx *ctx, int *a, int *b, double *delta, int capacity, int *count);
 

@@ -19,7 +19,7 @@ RESOURCE_EXHAUSTED, FAILED_PRECONDITION, UNIMPLEMENTED, INTERNAL, UNAVAILABLE = 
 EUC_2D, ATT, CEIL_2D = 0, 1, 2
 ELEM_AUTO, ELEM_F64, ELEM_I32 = 0, 1, 2
 OPT_ELEM, OPT_KERNEL, OPT_BATCH, OPT_WGS_PER_TOUR, OPT_HISTORY = 1, 2, 3, 4, 5
-OPT_GRAPH, OPT_TIMING, OPT_BLOCK, OPT_MAX_TOURS = 6, 7, 8, 9
+OPT_GRAPH, OPT_TIMING, OPT_BLOCK, OPT_MAX_TOURS, OPT_DEPTH = 6, 7, 8, 9, 10
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -56,6 +56,7 @@ SIGNATURES = {
     "tspgpu_time_sweep": (C.c_int, [_ctx, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "tspgpu_time_build": (C.c_int, [_ctx, C.c_int, C.POINTER(C.c_float)]),
     "tspgpu_timing_read": (C.c_int, [_ctx, _pd, _pl, C.c_int]),
+    "tspgpu_debug_stamps": (C.c_int, [_ctx, C.c_void_p, C.c_int]),
     "tspgpu_history": (C.c_int, [_ctx, _ip, _ip, _dp, C.c_int, _pi]),
 }
 

@@ -39,6 +39,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "tspgpu.h"
@@ -71,11 +72,13 @@ template <> struct Elem<double> {
     typedef v2f64 vec;
     static constexpr int V = 2;
     __device__ static double lim() { return DBL_MAX; }
+    __device__ static double big() { return 1.0e300; }   // poison: above any real delta, sums stay finite
 };
 template <> struct Elem<int> {
     typedef v4i32 vec;
     static constexpr int V = 4;
     __device__ static int lim() { return INT_MAX; }
+    __device__ static int big() { return 1 << 29; }      // poison; real costs < 2^27 so |delta| < 2^28
 };
 
 __device__ __forceinline__ double vget(const v2f64 &v, int i) { return v[i]; }
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__
     *reinterpret_cast<VT *>(out + (size_t)i * ld + j0) = o;
 }
 
-// ingest of a caller matrix: flags[0] = some entry is not an int in [-1, 2^28),
+// ingest of a caller matrix: flags[0] = some entry is not an int in [-1, 2^27),
 // flags[1] = some c[i][j] != c[j][i]
 __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, int n, int ld, int *flags)
 {
@@ -164,7 +167,7 @@ __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, i
     if (j >= n) return;
     const double x = m[(size_t)i * ld + j];
     const double r = __builtin_trunc(x);
-    if (!(r == x && x >= -1.0 && x < 268435456.0)) flags[0] = 1;
+    if (!(r == x && x >= -1.0 && x < 134217728.0)) flags[0] = 1;
     if (j > i && m[(size_t)j * ld + i] != x) flags[1] = 1;
 }
 
@@ -186,12 +189,25 @@ __global__ void __launch_bounds__(256) k_i32_to_f64(const int *__restrict__ m, i
 
 // ---------------------------------------------------------------------------
 // tour state (structure of arrays over tour slots)
+//
+//   ord[p]   node at array position p
+//   pos[v]   inverse of ord
+//   dpos[p]  cost of the tour edge between array positions p and p+1 (cyclic),
+//            in the tour's current direction
+//   dir      +1: succ(ord[p]) = ord[p+1];  -1: succ(ord[p]) = ord[p-1]
+//
+// A 2-opt move flips one of the two arcs the removed edges cut the cycle into.
+// ref_reverse_path flips the arc succ_a .. b; flipping the OTHER arc and
+// toggling `dir` yields the identical successor function, so k_apply always
+// reverses the shorter arc (<= n/2 array cells).  Reversing an array range also
+// reverses the order of the edge costs inside it, and only the two boundary
+// edges {a,b}, {succ_a,succ_b} are new: two matrix reads per move.
 // ---------------------------------------------------------------------------
 struct Tours {
-    int *ord, *pos, *succ;   // [cap][n]
-    double *dnext;           // [cap][n] 8-byte slots; int32 mode uses the first 4n bytes of each
+    int *ord, *pos, *succ;   // [cap][n]; succ is filled on export only
+    double *dpos;            // [cap][n] 8-byte slots; int32 mode uses the first 4n bytes of each
     double *cost, *last_delta; // [cap]
-    int *done, *nsweeps, *cap_sweeps, *status; // [cap]
+    int *dir, *done, *nsweeps, *cap_sweeps, *status; // [cap]
     Partial *partial;        // [cap][MAX_WGS_PER_TOUR]
 };
 
@@ -203,13 +219,15 @@ struct TabuState {           // device-resident, slot 0 only
 struct HistBuf { int *a, *b; double *d; int cap; };
 
 template <typename T>
-__device__ __forceinline__ T *dnext_of(const Tours &S, int t, int n)
+__device__ __forceinline__ T *dpos_of(const Tours &S, int t, int n)
 {
-    return reinterpret_cast<T *>(S.dnext + (size_t)t * n);
+    return reinterpret_cast<T *>(S.dpos + (size_t)t * n);
 }
 
+__device__ __forceinline__ int wrap(int p, int n) { return p < 0 ? p + n : (p >= n ? p - n : p); }
+
 // ---------------------------------------------------------------------------
-// k_tour_init: ord[] given; derive pos/succ/dnext and the cost exactly as
+// k_tour_init: ord[] given (dir = +1); derive pos/dpos and the cost exactly as
 // ref_2opt recomputes it (src/algorithms/refinment.c:6-9): sum over NODE index
 // i = 0..n-1 of c[i][succ i], accumulated in that order (doubles), so that
 // non-integer matrices give the same bits.  One workgroup per tour.
@@ -221,20 +239,19 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     __shared__ double chunk[1024];
     const int t = slot0 + blockIdx.x;
     const int *ord = S.ord + (size_t)t * n;
-    int *pos = S.pos + (size_t)t * n, *succ = S.succ + (size_t)t * n;
-    T *dn = dnext_of<T>(S, t, n);
+    int *pos = S.pos + (size_t)t * n;
+    T *dp = dpos_of<T>(S, t, n);
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
         const int node = ord[p];
         const int s = ord[p + 1 == n ? 0 : p + 1];
         pos[node] = p;
-        succ[node] = s;
-        dn[node] = mat[(size_t)node * ld + s];
+        dp[p] = mat[(size_t)node * ld + s];
     }
     __syncthreads();
     double total = 0;
     if constexpr (sizeof(T) == 4) {
         long long part = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) part += dn[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) part += dp[i];
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
         long long *acc = reinterpret_cast<long long *>(chunk);
         if ((threadIdx.x & 63) == 0) acc[threadIdx.x >> 6] = part;
@@ -247,7 +264,7 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     } else {
         for (int base = 0; base < n; base += 1024) {
             const int m = min(1024, n - base);
-            for (int i = threadIdx.x; i < m; i += blockDim.x) chunk[i] = dn[base + i];
+            for (int i = threadIdx.x; i < m; i += blockDim.x) chunk[i] = dp[pos[base + i]]; // c[i][succ i]
             __syncthreads();
             if (threadIdx.x == 0)
                 for (int i = 0; i < m; i++) total += chunk[i];
@@ -257,11 +274,22 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     if (threadIdx.x == 0) {
         S.cost[t] = total;
         S.last_delta[t] = 0;
+        S.dir[t] = 1;
         S.done[t] = 0;
         S.nsweeps[t] = 0;
         S.cap_sweeps[t] = caps ? caps[blockIdx.x] : -1;
         S.status[t] = 0;
     }
+}
+
+// successor array for the host (tsp_solution.path): succ[ord[p]] = ord[p + dir]
+__global__ void __launch_bounds__(256) k_export_succ(Tours S, int n, int slot0)
+{
+    const int t = slot0 + blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int *ord = S.ord + (size_t)t * n;
+    S.succ[(size_t)t * n + ord[p]] = ord[wrap(p + S.dir[t], n)];
 }
 
 // ---------------------------------------------------------------------------
@@ -325,8 +353,10 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
 struct SweepArgs {
     Tours S;
     const void *mat;
-    int n, ld, slot0, P;     // P = tour positions per workgroup
+    int n, ld, slot0, P;     // P = array positions (tour edges) per workgroup
     int symmetric;
+    int ablate;              // diagnostics only: 1 = no pair evaluation, 2 = no row traffic (results are wrong)
+    unsigned long long *stamps; // diagnostics only: 64 wall-clock stamps (10 ns ticks) per workgroup, or null
     const int *tabu_list;    // TABU only
     const TabuState *tabu;   // TABU only
 };
@@ -361,11 +391,12 @@ __device__ __forceinline__ bool is_tabu(const int *tl, int node, int iter, int t
 }
 
 // ---------------------------------------------------------------------------
-// K2/K3 "simple" sweep: one LDS row.  Workgroup g walks tour positions
-// [g*P, (g+1)*P); for position p: a = ord[p], sa = ord[p+1].  Row sa is staged
-// in LDS (gather target c[sa][sb]); row a is read coalesced from global; succ[]
-// and dnext[] come from L2.  Used when three rows do not fit in LDS, and as an
-// independent cross-check of the pipelined kernel.
+// K2/K3 "simple" sweep: one LDS row.  Workgroup g walks array positions
+// [g*P, (g+1)*P); each position p is one tour edge (a, sa) = (ord[p], ord[p+1])
+// (or the reverse when dir < 0).  Row sa is staged in LDS (gather target
+// c[sa][sb]); row a is read coalesced from global; pos/ord/dpos come from L2.
+// Used when three rows do not fit in LDS, and as an independent cross-check of
+// the pipelined kernel.
 // ---------------------------------------------------------------------------
 template <typename T, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
@@ -381,8 +412,9 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)ld * sizeof(T));
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
-    const int *succ = A.S.succ + (size_t)t * n;
-    const T *dn = dnext_of<T>(A.S, t, n);
+    const int *pos = A.S.pos + (size_t)t * n;
+    const T *dp = dpos_of<T>(A.S, t, n);
+    const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
@@ -393,9 +425,9 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     const int p0 = blockIdx.x * A.P;
     const int cnt = min(A.P, n - p0);
     for (int s = 0; s < cnt; s++) {
-        const int p = p0 + s;
-        const int a = ord[p];
-        const int sa = ord[p + 1 == n ? 0 : p + 1];
+        const int p = p0 + s, p1 = p + 1 == n ? 0 : p + 1;
+        const int a = dir > 0 ? ord[p] : ord[p1];
+        const int sa = dir > 0 ? ord[p1] : ord[p];
         __syncthreads();
         {
             const VT *src = reinterpret_cast<const VT *>(mat + (size_t)sa * ld);
@@ -406,20 +438,21 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
         if constexpr (TABU) {
             if (is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure)) continue;
         }
-        const T d_a = dn[a];
+        const T d_a = dp[p];
         const T *rowA = mat + (size_t)a * ld;
         const int kmax = A.symmetric ? n / 2 : n - 1 - a;
         for (int k = 1 + tid; k <= kmax; k += BT) {
             int b = a + k;
             if (b >= n) b -= n;
-            const int sb = succ[b];
+            const int q = pos[b];
+            const int sb = ord[wrap(q + dir, n)];
             if (b == sa || sb == a) continue;          // refinment.c:55
             if (!pair_owned(a, b, n, A.symmetric)) continue;
             if constexpr (TABU) {
                 if (is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure)) continue;
             }
-            const T made = rowA[b] + rowS[sb];         // c[a][b] + c[sa][sb]
-            const T kept = d_a + dn[b];                // c[a][sa] + c[b][sb]
+            const T made = rowA[b] + rowS[sb];                      // c[a][b] + c[sa][sb]
+            const T kept = d_a + dp[dir > 0 ? q : wrap(q - 1, n)];  // c[a][sa] + c[b][sb]
             consider<T>(made - kept, a, b, best_d, best_key);
         }
     }
@@ -435,19 +468,21 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
 
 // ---------------------------------------------------------------------------
 // K2/K3 "pipelined" sweep: the speed-of-light form for rows that fit LDS three
-// times.  Workgroup g walks a run of cnt consecutive tour positions and needs
-// the cnt+1 matrix rows of the nodes on that run, each exactly once:
+// times.  Workgroup g owns a run of cnt consecutive tour edges and needs the
+// cnt+1 matrix rows of the nodes on that run, each exactly once:
 //     row r   (node a)  : c[a][b], read conflict-free from LDS at the thread's
 //                         OWN b's (b fixed per thread for the whole kernel, so
-//                         succ[b], dnext[b] live in registers)
+//                         succ b and c[b][succ b] live in registers)
 //     row r+1 (node sa) : c[sa][succ b], random LDS gather
-//     row r+2, r+3      : in flight from HBM in registers (two rows deep),
-//                         written to the third LDS buffer at the end of the step
+//     rows r+2 .. r+1+D : in flight from HBM in D register sets; one of them is
+//                         written to the third LDS buffer at the end of a step
+//                         and its registers are re-issued for row r+2+D
 // so every matrix byte is fetched once per sweep (+1 row per run) with 16-byte
-// coalesced loads, and one barrier separates steps.  Both orientations of a
-// pair meet in LDS; pair_owned() keeps one.
+// coalesced loads, up to D rows per workgroup are in flight at any time, and
+// one barrier separates steps.  Both orientations of a pair meet in LDS;
+// pair_owned() keeps one.
 // ---------------------------------------------------------------------------
-template <typename T, int NCH, bool TABU>
+template <typename T, int NCH, int D, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 {
     typedef typename Elem<T>::vec VT;
@@ -459,136 +494,202 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nvec = ld / V; // 16-byte vectors per row
 
-    T *buf = reinterpret_cast<T *>(smem);                                  // 3 * ld
-    int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)); // P + 1 (+pad)
-    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + (size_t)((A.P + 1 + 3) & ~3) * 4);
+    // LDS: 3 row buffers | nodes[-1 .. P] | dcell[2] | reduction scratch
+    T *buf = reinterpret_cast<T *>(smem);
+    int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)) + 1; // nodes[-1] = node before the run
+    const size_t nodes_bytes = (size_t)((A.P + 2 + 3) & ~3) * 4;
+    T *dcell = reinterpret_cast<T *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes);
+    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes + 16);
 
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
-    const int *succ = A.S.succ + (size_t)t * n;
-    const T *dnx = dnext_of<T>(A.S, t, n);
+    const int *pos = A.S.pos + (size_t)t * n;
+    const T *dp = dpos_of<T>(A.S, t, n);
+    const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
 
+    unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
+#define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
+    STAMP(0);
     const int p0 = blockIdx.x * A.P;
     const int cnt = min(A.P, n - p0);
     // (host guarantees cnt >= 1 for every launched workgroup)
-    for (int i = tid; i <= cnt; i += BT) {
-        int p = p0 + i;
-        if (p >= n) p -= n;
-        nodes[i] = ord[p];
-    }
+    // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
+    for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
 
-    // per-thread state of the owned b's
-    int sbv[NCH][V];
+    // per-thread state of the owned b's: LDS byte offset of succ b, and c[b][succ b].
+    // A b that can never be part of a move from this thread (pad lane, tabu) gets the poison
+    // value instead, which drives every delta it takes part in far above any real one.
+    // Load order: pos[b] and the run's nodes first (one round trip), then the matrix rows are
+    // issued, and only then the loads that depend on pos[b]: two dependent trips, not three.
+    const T BIG = Elem<T>::big();
+    int sboff[NCH][V];
     T dnv[NCH][V];
-    bool skipb[NCH][V];
+    int q[NCH][V];
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    for (int c = 0; c < NCH; c++)
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int b = (c * BT + tid) * V + v;
-            if (b < n) {
-                const int s = succ[b];
-                sbv[c][v] = s;
-                dnv[c][v] = dnx[b];
-                bool sk = false;
-                if constexpr (TABU) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, s, iter, tenure);
-                skipb[c][v] = sk;
-            } else {
-                sbv[c][v] = 0; dnv[c][v] = 0; skipb[c][v] = true;
-            }
+            q[c][v] = b < n ? pos[b] : 0;
         }
-    }
     __syncthreads(); // nodes[] visible
+    STAMP(1);
 
-    VT R0[NCH], R1[NCH];
-    auto issue = [&](VT(&R)[NCH], int r) __attribute__((always_inline)) {
-        // branch-free: lanes past the row end re-read its last vector (and later
-        // re-write the same bytes), which keeps R[] in registers
-        // Past the end of the run (r > cnt) every lane re-reads one hot vector instead:
-        // the number of loads in flight is then the same on every path, which lets
-        // hipcc place exact counted vmcnt waits in front of the LDS writes.
+    VT R[D][NCH];
+    auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        // Branch-free.  Lanes past the row end re-read its last vector (and later re-write
+        // the same bytes).  Past the end of the run (r > cnt) every lane re-reads one hot
+        // vector instead: the number of loads in flight is then the same on every path,
+        // which lets hipcc place exact counted vmcnt waits in front of the LDS writes.
         const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
-        const int lim = r <= cnt ? nvec - 1 : 0;
+        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
 #pragma unroll
-        for (int c = 0; c < NCH; c++) R[c] = src[min(c * BT + tid, lim)];
+        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
     };
-    auto land = [&](const VT(&R)[NCH], int slot) __attribute__((always_inline)) {
+    auto land = [&](const VT(&Rs)[NCH], int slot) __attribute__((always_inline)) {
         VT *dst = reinterpret_cast<VT *>(buf + (size_t)slot * ld);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[c];
+        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
+    };
+    // row r travels through register set r % D
+#pragma unroll
+    for (int r = 0; r < D; r++) issue(R[r], r);
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            const int sb = ord[wrap(q[c][v] + dir, n)];
+            T dn = dp[dir > 0 ? q[c][v] : wrap(q[c][v] - 1, n)];
+            bool sk = b >= n;
+            if constexpr (TABU)
+                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
+            sboff[c][v] = sb * (int)sizeof(T);
+            dnv[c][v] = sk ? -BIG : dn;   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+        }
+    // prep(s): make the landed row of a_s ready to be the "row a" buffer of step s.  The
+    // three pairs the reference skips (refinment.c:55: b == a, b == succ a, succ b == a,
+    // i.e. b in {a_s, a_s+1, a_s-1}) are removed by poisoning their c[a][b] cells, after
+    // c[a][succ a] has been saved for the step.  One lane; runs while the row is still
+    // only a gather target (step s-1): the cells it touches are read there only by pairs
+    // that are poisoned themselves.
+    auto prep = [&](int s) __attribute__((always_inline)) {
+        if (tid == 0 && s < cnt) {
+            T *row = buf + (size_t)(s % 3) * ld;
+            const int am = nodes[s - 1], a0 = nodes[s], ap = nodes[s + 1];
+            dcell[s & 1] = row[ap];
+            row[am] = BIG; row[a0] = BIG; row[ap] = BIG;
+        }
     };
 
-    issue(R0, 0);
-    issue(R1, 1);
-    land(R0, 0);
-    land(R1, 1);
-    issue(R0, 2);
-    issue(R1, 3);
+    land(R[0], 0);
+    land(R[1 % D], 1);
+    issue(R[0], D);
+    issue(R[1 % D], D + 1);
     __syncthreads();
+    prep(0);
+    __syncthreads();
+    STAMP(2);
 
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     T best_d = TABU ? Elem<T>::lim() : (T)0;
-    u64 best_key = TABU ? KEY_NONE : 0;
+    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
+    bool have = false;
 
-    const int half = n / 2;
-    auto step = [&](int s, VT(&R)[NCH]) __attribute__((always_inline)) {
-        const int a = nodes[s], sa = nodes[s + 1];
+    auto eval = [&](auto check_tag, int a, const VT &xa, const T(&g)[V], const T(&dn)[V], T d_a, int b0, int lo, int len)
+        __attribute__((always_inline)) {
+        constexpr bool CHECK = decltype(check_tag)::value;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = b0 + v;
+            T delta;
+            if constexpr (sizeof(T) == 4) delta = vget(xa, v) + g[v] - (d_a + dn[v]);
+            else { const T made = vget(xa, v) + g[v]; const T kept = d_a + dn[v]; delta = made - kept; } // refinment.c:58-60
+            bool ok = true;
+            if constexpr (CHECK) {
+                int tt = b - lo;
+                tt += (tt >> 31) & n;
+                ok = (unsigned)tt < (unsigned)len;
+            }
+            const bool lt = ok & (delta < best_d);
+            bool eq = ok & (delta == best_d);
+            if constexpr (!TABU) eq &= delta < (T)0;
+            if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                if (eq) {
+                    const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                    const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                   : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                    if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                }
+            }
+            best_d = lt ? delta : best_d;
+            best_a = lt ? a : best_a;
+            best_b = lt ? b : best_b;
+            have = have | lt;
+        }
+    };
+
+    auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
         const T *bA = buf + (size_t)(s % 3) * ld;
-        const T *bS = buf + (size_t)((s + 1) % 3) * ld;
-        bool live = true;
-        if constexpr (TABU) live = !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
+        bool live = A.ablate != 1;
+        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, nodes[s + 1], iter, tenure));
         if (live) {
-            const T d_a = bA[sa]; // c[a][sa]
-            // index range (cyclic) that pair_owned() can accept from a: [a+1, a+half] / (a, n)
-            const int lo = a + 1;
-            const int hi = A.symmetric ? a + half : n - 1;
+            const T d_a = dcell[s & 1]; // c[a][succ a]
+            // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
+            // (pair_owned(): half way round the index circle; ties at n/2 go to the lower a)
+            const int lo = a + 1 == n ? 0 : a + 1;
+            const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
-                const int w0 = (c * BT + (tid & ~63)) * V;      // this wave's first b in chunk c
-                const int w1 = w0 + 64 * V - 1;
-                const bool hit = hi < n ? (w0 <= hi && w1 >= lo) : (w1 >= lo || w0 <= hi - n);
-                if (!hit) continue;                             // wave-uniform
+                const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
+                if (w0 >= n) continue;                          // pad wave
+                int t0 = w0 - lo;
+                if (t0 < 0) t0 += n;
+                const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
+                const bool inside = nowrap && t0 + 64 * V <= len;
+                const bool outside = nowrap && t0 >= len;
+                if (outside) continue;                          // wave-uniform
                 const int b0 = (c * BT + tid) * V;
                 // all LDS reads of the chunk first (lanes past the row read its last vector;
-                // their results are masked by skipb), then branch-free arithmetic
+                // their dn is poisoned), then the arithmetic
                 const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
                 T g[V];
 #pragma unroll
-                for (int v = 0; v < V; v++) g[v] = bS[sbv[c][v]];
-#pragma unroll
-                for (int v = 0; v < V; v++) {
-                    const int b = b0 + v;
-                    const int sb = sbv[c][v];
-                    const T made = vget(xa, v) + g[v];          // c[a][b] + c[sa][sb]
-                    const T kept = d_a + dnv[c][v];             // c[a][sa] + c[b][sb]
-                    const T delta = made - kept;
-                    int k = b - a;
-                    k += (k >> 31) & n;                         // (b - a) mod n
-                    const int k2 = 2 * k;
-                    const bool mine = A.symmetric ? ((k2 < n) | ((k2 == n) & (a < b))) : (b > a);
-                    const bool ok = (!skipb[c][v]) & (k != 0) & (b != sa) & (sb != a) & mine & (delta <= best_d);
-                    if (ok) consider<T>(delta, a, b, best_d, best_key);
-                }
+                for (int v = 0; v < V; v++) g[v] = *reinterpret_cast<const T *>(bS + sboff[c][v]);
+                if (inside) eval(std::false_type{}, a, xa, g, dnv[c], d_a, b0, lo, len);
+                else eval(std::true_type{}, a, xa, g, dnv[c], d_a, b0, lo, len);
             }
         }
-        if (s + 2 <= cnt) land(R, (s + 2) % 3);
-        issue(R, s + 4);
+        if (stamp && tid == 0 && s < 24) stamp[8 + 2 * s] = wall_clock64();      // compute done
+        prep(s + 1);
+        if (s + 2 <= cnt) land(Rs, (s + 2) % 3);
+        issue(Rs, s + 2 + D);
         __syncthreads();
+        if (stamp && tid == 0 && s < 24) stamp[9 + 2 * s] = wall_clock64();      // row landed, barrier passed
     };
 
     {
         int s = 0;
-        for (; s + 1 < cnt; s += 2) { // unconditional body: exact vmcnt accounting
-            step(s, R0);
-            step(s + 1, R1);
+        for (; s + D <= cnt; s += D) { // unconditional body: exact vmcnt accounting
+#pragma unroll
+            for (int u = 0; u < D; u++) step(s + u, R[(u + 2) % D]);
         }
-        if (s < cnt) step(s, R0);
+#pragma unroll
+        for (int u = 0; u < D; u++)
+            if (s + u < cnt) step(s + u, R[(u + 2) % D]);
     }
 
+    STAMP(3);
+    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
     double d = (double)best_d;
-    u64 key = best_key;
+    u64 key;
+    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
@@ -596,18 +697,20 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     }
 }
 
+
 // ---------------------------------------------------------------------------
 // K4 apply: one workgroup per tour.  Reduces the per-workgroup partials to the
-// global (delta, a, b), applies the move as a cyclic reversal of positions
-// pos[a]+1 .. pos[b] (= ref_reverse_path's segment succ_a .. b), refreshes
-// succ/dnext on the touched span, updates cost, sweep counter, done flag.
+// global (delta, a, b) and applies the move (see the Tours comment): reverse the
+// shorter arc in ord/pos/dpos, toggle dir when that arc is not ref_reverse_path's
+// succ_a .. b, write the two new boundary edge costs, update cost / sweep
+// counter / done flag.  Four dependent memory round trips.
 // TABU: always applies the best admissible move, stamps the tabu list, keeps
 // the incumbent and advances the linear tenure policy.
 // ---------------------------------------------------------------------------
 struct ApplyArgs {
     Tours S;
     const void *mat;
-    int n, ld, slot0, G;
+    int n, ld, slot0, G, symmetric;
     int *tabu_list;      // TABU
     TabuState *tabu;     // TABU
     int *best_succ;      // TABU resident incumbent
@@ -639,30 +742,52 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
     const bool move = TABU ? (key != KEY_NONE) : (d < TWO_OPT_EPS);
     const int a = (int)(key >> 32), b = (int)(key & 0xffffffffu);
 
-    int *ord = A.S.ord + (size_t)t * n, *pos = A.S.pos + (size_t)t * n, *succ = A.S.succ + (size_t)t * n;
+    int *ord = A.S.ord + (size_t)t * n, *pos = A.S.pos + (size_t)t * n;
+    T *dp = dpos_of<T>(A.S, t, n);
+    const int dir = A.S.dir[t];
+    int ndir = dir; // direction after this move
     int sa = -1, sb = -1;
     if (move) {
         const int i = pos[a], j = pos[b];
-        sa = succ[a]; sb = succ[b];
-        int L = j - i;
-        if (L < 0) L += n; // positions i+1 .. i+L hold succ_a .. b
-        __syncthreads();   // everybody has read pos/succ before they change
-        for (int k = tid; k < L / 2; k += BT) {
-            int p = i + 1 + k; if (p >= n) p -= n;
-            int q = j - k;     if (q < 0) q += n;
-            const int u = ord[p], v = ord[q];
-            ord[p] = v; ord[q] = u;
-            pos[v] = p; pos[u] = q;
+        // forward arc succ_a .. b = positions i+dir, i+2dir, .., j  (L cells)
+        int L = (j - i) * dir;
+        if (L < 0) L += n;
+        // flip the shorter arc; flipping the other one (succ_b .. a) needs dir toggled.
+        // A non-symmetric matrix keeps the reference's arc: its edge costs are direction bound.
+        const bool other = A.symmetric && (n - L < L);
+        const int M = other ? n - L : L;
+        const int first = other ? wrap(j + dir, n) : wrap(i + dir, n); // forward-first cell of the arc
+        const int lo = dir > 0 ? first : wrap(first - (M - 1), n);     // lowest array cell of the arc
+        // old neighbours of the arc (all read before anything moves)
+        const int x0 = ord[wrap(lo - 1, n)], x1 = ord[lo];
+        const int x2 = ord[wrap(lo + M - 1, n)], x3 = ord[wrap(lo + M, n)];
+        sa = ord[wrap(i + dir, n)];
+        sb = ord[wrap(j + dir, n)];
+        // cells: swap k <-> M-1-k ; inner edges (M-1 of them): swap k <-> M-2-k
+        __syncthreads(); // everybody has read pos/ord before they change
+        for (int k = tid; k < M / 2; k += BT) {
+            const int pk = wrap(lo + k, n), qk = wrap(lo + M - 1 - k, n);
+            const int u = ord[pk], v = ord[qk];
+            ord[pk] = v; ord[qk] = u;
+            pos[v] = pk; pos[u] = qk;
         }
-        __syncthreads();
-        T *dn = dnext_of<T>(A.S, t, n);
-        for (int k = tid; k <= L; k += BT) { // a, the reversed span; its last node now precedes sb
-            int p = i + k; if (p >= n) p -= n;
-            const int node = ord[p];
-            const int s = ord[p + 1 == n ? 0 : p + 1];
-            succ[node] = s;
-            dn[node] = mat[(size_t)node * ld + s];
+        if (A.symmetric) {
+            for (int k = tid; k < (M - 1) / 2; k += BT) {
+                const int pe = wrap(lo + k, n), qe = wrap(lo + M - 2 - k, n);
+                const T eu = dp[pe], ev = dp[qe];
+                dp[pe] = ev; dp[qe] = eu;
+            }
+            if (tid == 0) dp[wrap(lo - 1, n)] = mat[(size_t)x0 * ld + x2];
+            if (tid == 64 % BT) dp[wrap(lo + M - 1, n)] = mat[(size_t)x1 * ld + x3];
+        } else {
+            __syncthreads(); // cells final; re-read the costs of edges lo-1 .. lo+M-1 in tour direction
+            for (int k = tid; k <= M; k += BT) {
+                const int pe = wrap(lo - 1 + k, n);
+                const int un = ord[pe], vn = ord[wrap(pe + 1, n)];
+                dp[pe] = dir > 0 ? mat[(size_t)un * ld + vn] : mat[(size_t)vn * ld + un];
+            }
         }
+        if (other) { ndir = -dir; if (tid == 0) A.S.dir[t] = ndir; }
     }
     if constexpr (TABU) {
         TabuState *ts = A.tabu;
@@ -670,9 +795,9 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
         double cost_now = A.S.cost[t];
         if (move) cost_now += d;
         const bool improved = ts->resident && cost_now < ts->best_cost;
-        __syncthreads(); // succ[] final; all threads have read ts->iter / best_cost
+        __syncthreads(); // ord[]/dir final; all threads have read ts->iter / best_cost
         if (improved && A.best_succ)
-            for (int k = tid; k < n; k += BT) A.best_succ[k] = succ[k];
+            for (int p = tid; p < n; p += BT) A.best_succ[ord[p]] = ord[wrap(p + ndir, n)];
         if (tid == 0) {
             if (move) {
                 A.S.cost[t] = cost_now;
@@ -709,11 +834,11 @@ __global__ void k_copy_tour(Tours S, int n, int dst, int src)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         S.ord[(size_t)dst * n + i] = S.ord[(size_t)src * n + i];
         S.pos[(size_t)dst * n + i] = S.pos[(size_t)src * n + i];
-        S.succ[(size_t)dst * n + i] = S.succ[(size_t)src * n + i];
-        S.dnext[(size_t)dst * n + i] = S.dnext[(size_t)src * n + i];
+        S.dpos[(size_t)dst * n + i] = S.dpos[(size_t)src * n + i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.cost[dst] = S.cost[src]; S.last_delta[dst] = S.last_delta[src];
+        S.dir[dst] = S.dir[src];
         S.done[dst] = S.done[src]; S.nsweeps[dst] = S.nsweeps[src];
         S.cap_sweeps[dst] = S.cap_sweeps[src]; S.status[dst] = S.status[src];
     }
@@ -766,7 +891,9 @@ struct tspgpu_ctx {
     HistBuf hist{nullptr, nullptr, nullptr, 0};
 
     // launch plan
-    int plan_kernel = 0, plan_G = 0, plan_P = 0, plan_BT = 0, plan_NCH = 0, plan_T = 0;
+    int plan_kernel = 0, plan_G = 0, plan_P = 0, plan_BT = 0, plan_NCH = 0, plan_D = 0, plan_T = 0;
+    int opt_depth = 0, opt_ablate = 0, opt_stamps = 0;
+    unsigned long long *d_stamps = nullptr;
     size_t plan_lds = 0;
 
     std::vector<GraphEntry> graphs;
@@ -808,7 +935,7 @@ static void free_matrix(tspgpu_ctx *ctx)
 static void free_tours(tspgpu_ctx *ctx)
 {
     Tours &S = ctx->S;
-    void *ptrs[] = {S.ord, S.pos, S.succ, S.dnext, S.cost, S.last_delta, S.done, S.nsweeps, S.cap_sweeps, S.status,
+    void *ptrs[] = {S.ord, S.pos, S.succ, S.dpos, S.cost, S.last_delta, S.dir, S.done, S.nsweeps, S.cap_sweeps, S.status,
                     S.partial, ctx->d_starts, ctx->d_caps, ctx->d_tabu_list, ctx->d_best_succ, ctx->d_tabu};
     for (void *p : ptrs) if (p) hipFree(p);
     if (ctx->h_status) hipHostFree(ctx->h_status);
@@ -833,7 +960,8 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
     HIP_TRY(hipMalloc(&S.ord, T * N * 4));
     HIP_TRY(hipMalloc(&S.pos, T * N * 4));
     HIP_TRY(hipMalloc(&S.succ, T * N * 4));
-    HIP_TRY(hipMalloc(&S.dnext, T * N * 8));
+    HIP_TRY(hipMalloc(&S.dpos, T * N * 8));
+    HIP_TRY(hipMalloc(&S.dir, T * 4));
     HIP_TRY(hipMalloc(&S.cost, T * 8));
     HIP_TRY(hipMalloc(&S.last_delta, T * 8));
     HIP_TRY(hipMalloc(&S.done, T * 4));
@@ -873,15 +1001,31 @@ template <> const double *mat_of<double>(const tspgpu_ctx *ctx) { return ctx->d_
 template <> const int *mat_of<int>(const tspgpu_ctx *ctx) { return ctx->d_i32; }
 
 // --------------------------------------------------------------- launch plan
-template <typename T, int NCH, bool TABU> static const void *pipe_fn() { return (const void *)k_sweep_pipe<T, NCH, TABU>; }
+template <typename T, int NCH, int D, bool TABU> static const void *pipe_fn() { return (const void *)k_sweep_pipe<T, NCH, D, TABU>; }
 
-static const void *pipe_kernel(int elem, int nch, bool tabu)
+// register-prefetch depth per chunk count: D * NCH 16-byte vectors stay in flight per thread
+static int pipe_depth(int nch, int want) {
+    const int dmax = nch <= 1 ? 8 : nch <= 2 ? 4 : 2; // deeper sets would spill under the 128-VGPR cap
+    int d = want > 0 ? want : 2; // measured: deeper sets do not pay (the step is latency-, not bandwidth-bound)
+    d = d >= 8 ? 8 : d >= 4 ? 4 : 2;
+    return std::min(d, dmax);
+}
+
+static const void *pipe_kernel(int elem, int nch, int depth, bool tabu)
 {
-#define PK(T, N) (tabu ? pipe_fn<T, N, true>() : pipe_fn<T, N, false>())
+#define PK(T, N, DD) (tabu ? pipe_fn<T, N, DD, true>() : pipe_fn<T, N, DD, false>())
     if (elem == TSPGPU_ELEM_F64) {
-        switch (nch) { case 1: return PK(double, 1); case 2: return PK(double, 2); case 4: return PK(double, 4); }
+        switch (nch) {
+        case 1: return depth == 8 ? PK(double, 1, 8) : depth == 4 ? PK(double, 1, 4) : PK(double, 1, 2);
+        case 2: return depth == 4 ? PK(double, 2, 4) : PK(double, 2, 2);
+        case 4: return PK(double, 4, 2);
+        }
     } else {
-        switch (nch) { case 1: return PK(int, 1); case 2: return PK(int, 2); case 4: return PK(int, 4); }
+        switch (nch) {
+        case 1: return depth == 8 ? PK(int, 1, 8) : depth == 4 ? PK(int, 1, 4) : PK(int, 1, 2);
+        case 2: return depth == 4 ? PK(int, 2, 4) : PK(int, 2, 2);
+        case 4: return PK(int, 4, 2);
+        }
     }
 #undef PK
     return nullptr;
@@ -906,7 +1050,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     const size_t slack = 1024; // nodes[] + reduction scratch
 
     int BT = ctx->opt_block;
-    if (BT <= 0) BT = std::min(1024, std::max(64, pow2_ceil((nvec + 1) / 2)));
+    if (BT <= 0) BT = std::min(1024, std::max(64, pow2_ceil(nvec)));
     BT = std::min(1024, std::max(64, (BT + 63) & ~63));
 
     int kernel = ctx->opt_kernel;
@@ -915,9 +1059,14 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         return 3 * row + (size_t)(P + 4) * 4 + slack <= ctx->lds_max;
     };
     // provisional G / P
-    auto plan_GP = [&](size_t lds, int bt, int &G, int &P) {
+    auto plan_GP = [&](size_t lds, int bt, int &G, int &P, const void *fn) {
         int occ = (int)std::min<size_t>(ctx->lds_max / std::max<size_t>(lds, 1), (size_t)(2048 / bt));
+        int api = 0; // registers count too: ask the runtime for this very kernel
+        if (fn && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, fn, bt, lds) == hipSuccess && api > 0)
+            occ = std::min(occ, api);
         occ = std::max(1, std::min(occ, 8));
+        if (bt >= 1024) occ = 1; // measured: one 16-wave workgroup per CU beats two (tools/tune_sweep.py)
         G = ctx->opt_wgs > 0 ? ctx->opt_wgs : std::max(1, (ctx->cus * occ + ntours - 1) / ntours);
         G = std::min(G, MAX_WGS_PER_TOUR);
         G = std::min(G, std::max(1, n / 2));
@@ -935,19 +1084,20 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             kernel = 1;
         } else {
             nch = inst;
-            plan_GP(3 * row + slack, BT, G, P);
+            ctx->plan_D = pipe_depth(nch, ctx->opt_depth);
+            plan_GP(3 * row + slack, BT, G, P, pipe_kernel(ctx->elem, nch, ctx->plan_D, false));
             if (ctx->opt_wgs <= 0 && P < 8) { // each run fetches P+1 rows: keep the extra row under ~12 %
                 P = std::min(n, 8); G = (n + P - 1) / P;
             }
             while (!pipe_fits(BT, P) && G < MAX_WGS_PER_TOUR) { G *= 2; P = (n + G - 1) / G; G = (n + P - 1) / P; }
-            ctx->plan_lds = 3 * row + (size_t)((P + 1 + 3) & ~3) * 4 + 16 * sizeof(Partial) + 64;
+            ctx->plan_lds = 3 * row + (size_t)((P + 2 + 3) & ~3) * 4 + 16 + 16 * sizeof(Partial) + 64;
         }
     }
     if (kernel == 1) {
         if (row + slack > ctx->lds_max)
             return fail(ctx, E_EXHAUSTED, "matrix mode needs one %zu-byte row in LDS (max %zu): n=%d too large", row, ctx->lds_max, n);
         if (ctx->opt_block <= 0) BT = std::min(1024, std::max(64, pow2_ceil(nvec / 4)));
-        plan_GP(row + slack, BT, G, P);
+        plan_GP(row + slack, BT, G, P, simple_kernel(ctx->elem, false));
         ctx->plan_lds = row + 16 * sizeof(Partial) + 64;
         nch = 0;
     }
@@ -955,7 +1105,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
     // raise the dynamic-LDS cap of the kernels we are going to launch
     for (int tabu = 0; tabu < 2; tabu++) {
-        const void *fn = kernel == 2 ? pipe_kernel(ctx->elem, nch, tabu) : simple_kernel(ctx->elem, tabu);
+        const void *fn = kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
         if (!fn) return fail(ctx, E_INTERNAL, "no kernel instance for nch=%d", nch);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
     }
@@ -969,8 +1119,10 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
     A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.P = ctx->plan_P;
     A.symmetric = ctx->symmetric ? 1 : 0;
+    A.ablate = ctx->opt_ablate;
+    A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
-    const void *fn = ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, tabu) : simple_kernel(ctx->elem, tabu);
+    const void *fn = ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
     void *args[] = {&A};
     HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
     return E_OK;
@@ -982,6 +1134,7 @@ static int launch_apply(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, bool 
     A.S = ctx->S;
     A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.G = ctx->plan_G;
+    A.symmetric = ctx->symmetric ? 1 : 0;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
     A.best_succ = ctx->d_best_succ; A.trace = resident_tabu ? ctx->d_trace : nullptr;
     A.hist = ctx->hist;
@@ -1129,7 +1282,11 @@ static int load_path(tspgpu_ctx *ctx, int slot, const int *path, int cap)
 static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
 {
     const int n = ctx->n;
-    if (path) HIP_TRY(hipMemcpyAsync(path, ctx->S.succ + (size_t)slot * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (path) {
+        hipLaunchKernelGGL(k_export_succ, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, ctx->S, n, slot);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(path, ctx->S.succ + (size_t)slot * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     if (cost) HIP_TRY(hipMemcpyAsync(cost, ctx->S.cost + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (last_delta) HIP_TRY(hipMemcpyAsync(last_delta, ctx->S.last_delta + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1203,6 +1360,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_pts) hipFree(ctx->d_pts);
     if (ctx->d_flags) hipFree(ctx->d_flags);
     if (ctx->d_trace) hipFree(ctx->d_trace);
+    if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); }
     for (auto e : ctx->ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -1235,6 +1393,13 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_GRAPH: ctx->opt_graph = value ? 1 : 0; break;
     case TSPGPU_OPT_TIMING: ctx->opt_timing = value ? 1 : 0; break;
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
+    case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
+    case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 98: // undocumented: per-workgroup phase stamps of the pipelined sweep (single tour)
+        ctx->opt_stamps = value ? 1 : 0; drop_graphs(ctx);
+        if (value && !ctx->d_stamps) HIP_TRY(hipMalloc(&ctx->d_stamps, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
+        if (value) HIP_TRY(hipMemset(ctx->d_stamps, 0, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
+        break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
@@ -1254,6 +1419,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 6: return ctx->plan_BT;
     case 7: return ctx->symmetric ? 1 : 0;
     case 8: return ctx->cus;
+    case 9: return ctx->plan_D;
     }
     return -1;
 }
@@ -1333,7 +1499,7 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
     ctx->symmetric = flags[1] == 0;
     if (ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) {
         free_matrix(ctx);
-        return fail(ctx, E_INVALID, "int32 storage requested but the matrix is not integer-valued in [-1, 2^28)");
+        return fail(ctx, E_INVALID, "int32 storage requested but the matrix is not integer-valued in [-1, 2^27)");
     }
     ctx->elem = (ctx->opt_elem == TSPGPU_ELEM_F64 || !integral) ? TSPGPU_ELEM_F64 : TSPGPU_ELEM_I32;
     if (ctx->elem == TSPGPU_ELEM_I32) {
@@ -1662,6 +1828,16 @@ int tspgpu_timing_read(tspgpu_ctx *ctx, double *sweep_ms_total, long *sweep_laun
     if (sweep_ms_total) *sweep_ms_total = ctx->sweep_ms_total;
     if (sweep_launches) *sweep_launches = ctx->sweep_launches;
     if (reset) { ctx->sweep_ms_total = 0; ctx->sweep_launches = 0; }
+    return E_OK;
+}
+
+int tspgpu_debug_stamps(tspgpu_ctx *ctx, unsigned long long *out, int capacity_words)
+{
+    if (!ctx || !out || !ctx->d_stamps) return fail(ctx, E_PRECOND, "stamps not enabled");
+    hipSetDevice(ctx->device);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const size_t words = std::min<size_t>((size_t)capacity_words, (size_t)MAX_WGS_PER_TOUR * 64);
+    HIP_TRY(hipMemcpy(out, ctx->d_stamps, words * 8, hipMemcpyDeviceToHost));
     return E_OK;
 }
 
