@@ -1,0 +1,155 @@
+"""The C host layer (travellingsalesmanoptimization_amd/host): the reference's own entry
+points and CLI over the gfx950 engine.  CPU part: command-line parsing (the cases of the
+reference's test/main.c:13-69, which no longer compile there) and loud failure without a
+GPU.  GPU part: the `tsp` binary's -q stdout contract against the golden costs, the way
+scripts/compare_algs.py:67-72 drives the reference."""
+import ctypes as C
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "travellingsalesmanoptimization_amd", "host")
+TSP = os.path.join(HOST, "tsp")
+DATA = os.path.join(ROOT, "tests", "golden", "data")
+
+
+class Timespec(C.Structure):
+    _fields_ = [("tv_sec", C.c_long), ("tv_nsec", C.c_long)]
+
+
+class Solution(C.Structure):   # utils.h:42-47
+    _fields_ = [("cost", C.c_double), ("path", C.POINTER(C.c_int)), ("ncomp", C.c_int), ("comp", C.POINTER(C.c_int))]
+
+
+class Options(C.Structure):    # tsp.h:66-103
+    _fields_ = [("timelimit", C.c_double), ("seed", C.c_int), ("graph_random", C.c_bool), ("graph_input", C.c_bool),
+                ("inputfile", C.c_char_p), ("tofile", C.c_bool), ("k", C.c_int), ("policy", C.c_int),
+                ("mileage_init", C.c_int), ("bl_patching", C.c_bool), ("init_mip", C.c_bool), ("skip_policy", C.c_int),
+                ("callback_relaxation", C.c_bool), ("modified_costs", C.c_bool), ("hf_prob", C.c_double),
+                ("lb_dynk", C.c_bool), ("lb_initk", C.c_int), ("lb_improv", C.c_double), ("lb_delta", C.c_int),
+                ("lb_kstar", C.c_bool)]
+
+
+class Instance(C.Structure):   # tsp.h:115-134
+    _fields_ = [("alg", C.c_int), ("nnodes", C.c_int), ("c", Timespec), ("points", C.c_void_p), ("costs", C.c_void_p),
+                ("best_solution", Solution), ("starting_node", C.c_int), ("threads_seeds", C.c_void_p),
+                ("ncols", C.c_int), ("cplex_terminate", C.c_int)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    if not os.path.exists(os.path.join(HOST, "libtsphost.so")):
+        subprocess.run(["make", "-s", "-C", HOST], check=True)
+    return C.CDLL(os.path.join(HOST, "libtsphost.so"))
+
+
+def parse(host, *args):
+    argv = (C.c_char_p * (len(args) + 1))(b"tsp", *[a.encode() for a in args])
+    rc = host.tsp_parse_commandline(len(args) + 1, argv)
+    return rc, Options.in_dll(host, "tsp_env"), Instance.in_dll(host, "tsp_inst")
+
+
+def test_struct_layout_matches_reference_abi(host):
+    """x86-64 layout of the reference's structs (what code compiled against its headers expects)"""
+    # sizes printed by a program compiled against the reference headers: 32, 88, 96
+    assert C.sizeof(Solution) == 32 and C.sizeof(Options) == 88 and C.sizeof(Instance) == 96
+
+
+def test_cli_defaults_and_flags(host):
+    rc, env, inst = parse(host, "-n", "40", "-q")
+    assert rc == 0 and inst.nnodes == 40 and env.graph_random and not env.graph_input
+    assert env.timelimit == -1.0 and env.seed == -1 and env.k == 2147483647 and env.policy == 3  # tsp.c:6-44
+    assert inst.alg == 0 and inst.starting_node == 0
+
+    rc, env, inst = parse(host, "-file", os.path.join(DATA, "berlin52.tsp"), "-q")      # test/main.c "-file"
+    assert env.graph_input and env.inputfile.decode().endswith("berlin52.tsp")
+    rc, env, inst = parse(host, "-n", "10", "-time", "12.5", "-q")                        # test/main.c "-time"
+    assert env.timelimit == 12.5
+    rc, env, inst = parse(host, "-n", "10", "-seed", "123", "-q")                         # test/main.c "-seed"
+    assert env.seed == 123
+    rc, env, inst = parse(host, "-n", "10", "-t", "-3", "-q")
+    assert env.timelimit == -1.0                                                          # negative time ignored
+    for name, alg in [("GREEDY", 0), ("GREEDY_ITER", 1), ("2OPT_GREEDY", 2), ("TABU_SEARCH", 3), ("VNS", 4),
+                      ("CPLEX_NOSEC", 5), ("CPLEX_BENDERS", 6), ("EXTRA_MILEAGE", 7), ("CPLEX_BRANCH_CUT", 9),
+                      ("HARD_FIXING", 10), ("LOCAL_BRANCHING", 11)]:
+        rc, env, inst = parse(host, "-n", "10", "-alg", name, "-q")
+        assert inst.alg == alg
+    rc, env, inst = parse(host, "-n", "10", "-k", "200", "-skip", "2", "-q")
+    assert env.k == 2                                                                     # sic, tsp.c:237
+    rc, env, inst = parse(host, "-f", os.path.join(DATA, "berlin52.tsp"), "-n", "77", "-q")
+    assert env.graph_input and not env.graph_random and inst.nnodes != 77                 # -n ignored after -f
+    rc, env, inst = parse(host, "-n", "10", "--no_patching", "--no_relax", "--modify_costs", "--lb_dynk",
+                          "--lb_kstar", "-hf_prob", "0.4", "-lb_initk", "20", "-lb_delta", "7", "-lb_improv", "0.5",
+                          "-em", "RANDOM", "--to_file", "-q")
+    assert (not env.bl_patching and not env.callback_relaxation and env.modified_costs and env.lb_dynk and
+            env.lb_kstar and env.hf_prob == 0.4 and env.lb_initk == 20 and env.lb_delta == 7 and
+            env.lb_improv == 0.5 and env.mileage_init == 1 and env.tofile)
+
+
+def test_binary_help_and_missing_gpu():
+    import torch
+    r = subprocess.run([TSP, "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "-alg" in r.stdout
+    r = subprocess.run([TSP, "--all_algs"], capture_output=True, text=True)
+    assert "2OPT_GREEDY" in r.stdout and "TABU_SEARCH" in r.stdout
+    r = subprocess.run([TSP, "-f", "/nonexistent.tsp"], capture_output=True, text=True)
+    assert r.returncode == 1
+    if not torch.cuda.is_available():
+        r = subprocess.run([TSP, "-f", os.path.join(DATA, "berlin52.tsp"), "-alg", "GREEDY"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr   # loud, no silent host path
+
+
+def run_q(*args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([TSP, *args, "-q"], capture_output=True, text=True, timeout=600, env=e, cwd=ROOT)
+    return r.returncode, r.stdout.strip(), r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002"])
+def test_binary_greedy_and_iter(golden, name):
+    for alg, key in [("GREEDY", "greedy"), ("GREEDY_ITER", "greedy_iter")]:
+        rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", alg)
+        assert rc == 0, err
+        assert out == "Cost: %.2f" % golden["algs"][f"{name}_{key}"]["cost"]   # compare_algs.py:72 scrapes this
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002"])
+def test_binary_2opt_greedy(golden, name):
+    rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "2OPT_GREEDY")
+    assert rc == 0, err
+    assert out == "Cost: %.2f" % golden["algs"][f"{name}_2opt_greedy"]["cost"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100"])
+def test_binary_tabu_and_vns(golden, name, tmp_path):
+    os.makedirs(os.path.join(ROOT, "results"), exist_ok=True)
+    rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "TABU_SEARCH", "-k", "200")
+    assert rc == 0 and out == "Cost: %.2f" % golden["algs"][f"{name}_tabu_k200"]["cost"], err
+    lines = open(os.path.join(ROOT, "results", "TabuResults.dat")).read().split()
+    assert len(lines) == 200 and lines[0].startswith("0,")                       # metaheuristic.c:165
+    rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "VNS", "-k", "200")
+    assert rc == 0 and out == "Cost: %.2f" % golden["algs"][f"{name}_vns_k200"]["cost"], err
+
+
+@pytest.mark.gpu
+def test_binary_random_instance_and_deadline(golden):
+    rc, out, err = run_q("-n", "1000", "-seed", "123", "-alg", "GREEDY_ITER")
+    assert rc == 0 and out == "Cost: %.2f" % golden["algs"]["n1000_s123_greedy_iter"]["cost"], err
+    # a time limit ends the run with a valid incumbent and exit status 0 (DEADLINE_EXCEEDED is a success)
+    rc, out, err = run_q("-f", os.path.join(DATA, "fnl4461.tsp"), "-alg", "2OPT_GREEDY", "-t", "2")
+    assert rc == 0 and out.startswith("Cost: ")
+    assert 182566 <= float(out.split(":")[1]) < 229963      # between the optimum and NN(0)
+
+
+@pytest.mark.gpu
+def test_binary_rejects_att_like_the_reference():
+    rc, out, err = run_q("-f", os.path.join(DATA, "att48.tsp"), "-alg", "GREEDY")
+    assert rc == 1                                           # tsp.c:576-584
+    rc, out, err = run_q("-f", os.path.join(DATA, "att48.tsp"), "-alg", "2OPT_GREEDY", env={"TSP_ALLOW_EXT": "1"})
+    assert rc == 0 and float(out.split(":")[1]) >= 10628    # TSPLIB optimum of att48 as a bound

@@ -1,0 +1,226 @@
+/*
+ * tsp_core.c -- instance core of the host layer: globals, defaults, TSPLIB reader, random
+ * instances, validation, incumbent, and tsp_compute_costs running on the MI355X.
+ * Behaviour follows src/tsp.c of the reference (cited per function); the code is new.
+ */
+#include "tsp_model.h"
+
+#include <libgen.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "tspgpu.h"
+
+instance tsp_inst;
+options tsp_env;
+int tsp_edge_weight_kind = TSPGPU_EUC_2D;
+
+static struct tspgpu_ctx *g_ctx = NULL;
+
+struct tspgpu_ctx *tsp_gpu(void)
+{
+    if (!g_ctx) {
+        const char *dev = getenv("TSP_GPU_DEVICE");
+        tspgpu_ctx *c = NULL;
+        int rc = tspgpu_create(dev ? atoi(dev) : 0, &c);
+        if (rc != 0) {
+            log_fatal("no MI355X (gfx950) device available: tspgpu_create -> %d; there is no CPU fallback", rc);
+            return NULL;
+        }
+        g_ctx = c;
+    }
+    return g_ctx;
+}
+
+void tsp_gpu_release(void)
+{
+    if (g_ctx) tspgpu_destroy(g_ctx);
+    g_ctx = NULL;
+}
+
+/* defaults: tsp.c:6-44 */
+void tsp_init(void)
+{
+    memset(&tsp_env, 0, sizeof tsp_env);
+    tsp_env.timelimit = -1;
+    tsp_env.seed = -1;
+    tsp_env.k = __INT_MAX__;
+    tsp_env.policy = POL_LINEAR;
+    tsp_env.mileage_init = EM_MAX;
+    tsp_env.bl_patching = true;
+    tsp_env.init_mip = true;
+    tsp_env.skip_policy = BC_PROB;
+    tsp_env.callback_relaxation = true;
+    tsp_env.hf_prob = 0.7;
+    tsp_env.lb_initk = 10;
+    tsp_env.lb_improv = 0.02;
+    tsp_env.lb_delta = 10;
+
+    memset(&tsp_inst, 0, sizeof tsp_inst);
+    tsp_inst.nnodes = -1;
+    tsp_inst.best_solution.cost = __DBL_MAX__;
+    tsp_inst.alg = ALG_GREEDY;
+    tsp_inst.ncols = -1;
+    tsp_edge_weight_kind = TSPGPU_EUC_2D;
+
+    err_setverbosity(NORMAL);
+}
+
+/* tsp.c:468-481: glibc stream, x then y, node order */
+ERROR_CODE tsp_generate_randompoints(void)
+{
+    srand(tsp_env.seed);
+    tsp_inst.points = (point *)calloc((size_t)tsp_inst.nnodes, sizeof(point));
+    for (int i = 0; i < tsp_inst.nnodes; i++) {
+        tsp_inst.points[i].x = TSP_RAND();
+        tsp_inst.points[i].y = TSP_RAND();
+    }
+    tsp_edge_weight_kind = TSPGPU_EUC_2D;
+    return tsp_compute_costs();
+}
+
+/* tsp.c:527-606.  Same keyword handling (prefix match, tokens split on " :"), same fatal
+ * messages.  EDGE_WEIGHT_TYPE other than EUC_2D is fatal unless TSP_ALLOW_EXT=1. */
+void tsp_read_input(void)
+{
+    FILE *in = fopen(tsp_env.inputfile, "r");
+    if (!in) { log_fatal(" input file not found!"); tsp_handlefatal(); }
+
+    tsp_inst.nnodes = -1;
+    tsp_edge_weight_kind = TSPGPU_EUC_2D;
+    const char *ext = getenv("TSP_ALLOW_EXT");
+    const bool allow_ext = ext && atoi(ext) != 0;
+    bool coords = false;
+    char line[300];
+    while (fgets(line, sizeof line, in)) {
+        if (strlen(line) <= 1) continue;
+        char *key = strtok(line, " :");
+        if (!key) continue;
+        if (!strncmp(key, "DIMENSION", 9)) {
+            if (tsp_inst.nnodes >= 0) { log_fatal("two DIMENSION parameters in the file"); tsp_handlefatal(); }
+            tsp_inst.nnodes = atoi(strtok(NULL, " :"));
+            tsp_inst.points = (point *)calloc((size_t)tsp_inst.nnodes, sizeof(point));
+        } else if (!strncmp(key, "NODE_COORD_SECTION", 18)) {
+            if (tsp_inst.nnodes <= 0) { log_fatal("DIMENSION not found"); tsp_handlefatal(); }
+            coords = true;
+        } else if (!strncmp(key, "TYPE", 4)) {
+            if (strncmp(strtok(NULL, " :"), "TSP", 3)) { log_fatal(" format error:  only TSP file type accepted"); tsp_handlefatal(); }
+        } else if (!strncmp(key, "EDGE_WEIGHT_TYPE", 16)) {
+            const char *w = strtok(NULL, " :\n");
+            if (!strncmp(w, "EUC_2D", 6)) tsp_edge_weight_kind = TSPGPU_EUC_2D;
+            else if (allow_ext && !strncmp(w, "ATT", 3)) tsp_edge_weight_kind = TSPGPU_ATT;
+            else if (allow_ext && !strncmp(w, "CEIL_2D", 7)) tsp_edge_weight_kind = TSPGPU_CEIL_2D;
+            else { log_fatal(" format error:  only EDGE_WEIGHT_TYPE == EUC_2D managed"); tsp_handlefatal(); }
+        } else if (!strncmp(key, "EOF", 3)) {
+            break;
+        } else if (coords) {
+            const int idx = atoi(key) - 1;
+            const char *sx = strtok(NULL, " :,"), *sy = strtok(NULL, " :,");
+            if (idx >= 0 && idx < tsp_inst.nnodes && sx && sy) {
+                tsp_inst.points[idx].x = atof(sx);
+                tsp_inst.points[idx].y = atof(sy);
+            }
+        }
+    }
+    fclose(in);
+    ERROR_CODE e = tsp_compute_costs();
+    if (!err_ok(e)) log_error("code error: %d", e);
+}
+
+/* tsp.c:608-636 -> tspgpu_set_points + tspgpu_build_costs (k_build_costs).  tsp_inst.costs is
+ * still filled (row-major n x n doubles): the untouched CPLEX path and tsp_get_cost read it. */
+ERROR_CODE tsp_compute_costs(void)
+{
+    if (tsp_inst.nnodes <= 0) { log_fatal("computing costs of empty graph"); tsp_handlefatal(); }
+    struct tspgpu_ctx *g = tsp_gpu();
+    if (!g) return UNAVAILABLE;
+    const size_t n = (size_t)tsp_inst.nnodes;
+    int rc = tspgpu_set_points(g, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind);
+    if (rc) { log_error("tspgpu_set_points: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
+    free(tsp_inst.costs);
+    tsp_inst.costs = (double *)malloc(n * n * sizeof(double)); /* size_t: no int overflow past n = 46340 */
+    if (!tsp_inst.costs) return RESOURCE_EXHAUSTED;
+    rc = tspgpu_build_costs(g, tsp_inst.costs);
+    if (rc) { log_error("tspgpu_build_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
+    return T_OK;
+}
+
+double tsp_get_cost(int i, int j) { return tsp_inst.costs[(size_t)i * tsp_inst.nnodes + j]; }
+
+/* tsp.c:687-728 */
+bool tsp_is_tour(int path[], int n)
+{
+    if (n == 0) return false;
+    unsigned char *seen = (unsigned char *)calloc((size_t)n, 1);
+    int v = 0, steps = 0;
+    bool ok = true;
+    seen[0] = 1;
+    for (;;) {
+        const int nx = path[v];
+        if (nx < 0 || nx >= n) { ok = false; break; }
+        if (seen[nx]) { seen[nx] = 1; break; }
+        seen[nx] = 1;
+        v = nx;
+        if (++steps > n) { ok = false; break; }
+    }
+    for (int i = 0; ok && i < n; i++) if (!seen[i]) ok = false;
+    free(seen);
+    return ok;
+}
+
+/* tsp.c:642-667 */
+bool tsp_validate_solution(int nnodes, int *path)
+{
+    int *hits = (int *)calloc((size_t)nnodes, sizeof(int));
+    bool ok = true;
+    for (int i = 0; i < nnodes && ok; i++) {
+        if (path[i] < 0 || path[i] >= nnodes) ok = false; else hits[path[i]]++;
+    }
+    for (int i = 0; i < nnodes && ok; i++) if (hits[i] != 1) ok = false;
+    free(hits);
+    return ok && tsp_is_tour(path, nnodes);
+}
+
+/* tsp.c:669-684: strict <, T_OK / CANCELLED / INVALID_ARGUMENT */
+ERROR_CODE tsp_update_best_solution(tsp_solution *cur)
+{
+    if (!tsp_validate_solution(tsp_inst.nnodes, cur->path)) {
+        log_error("You tried to update best_solution with an unvalid solution");
+        return INVALID_ARGUMENT;
+    }
+    if (cur->cost < tsp_inst.best_solution.cost) {
+        memcpy(tsp_inst.best_solution.path, cur->path, (size_t)tsp_inst.nnodes * sizeof(int));
+        tsp_inst.best_solution.cost = cur->cost;
+        log_info("new best solution: %f", cur->cost);
+        return T_OK;
+    }
+    log_debug("discarded cost: %.2f", cur->cost);
+    return CANCELLED;
+}
+
+/* tsp.c:730-736 */
+double tsp_solution_cost(int path[])
+{
+    double c = 0;
+    for (int i = 0; i < tsp_inst.nnodes; i++) c += tsp_get_cost(i, path[i]);
+    return c;
+}
+
+void tsp_free_instance(void)
+{
+    utils_safe_free(tsp_env.inputfile);
+    utils_safe_free(tsp_inst.points);
+    utils_safe_free(tsp_inst.costs);
+    utils_safe_free(tsp_inst.best_solution.path);
+    utils_safe_free(tsp_inst.best_solution.comp);
+    utils_safe_free(tsp_inst.threads_seeds);
+    tsp_gpu_release();
+}
+
+void tsp_handlefatal(void)
+{
+    log_warn("fatal error detected, shutting down application");
+    tsp_free_instance();
+    exit(EXIT_FAILURE);
+}

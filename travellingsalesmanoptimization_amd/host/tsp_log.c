@@ -1,0 +1,119 @@
+/*
+ * tsp_log.c -- logging, the stdout contract of the binary, clock and small utilities of the
+ * host layer (behaviour of src/utils/errors.c and src/utils/utils.c; new code).
+ * The -q output ("Cost: %.2f" / "Time: %.2f") is what scripts/compare_algs.py:72,113 scrapes.
+ */
+#include "tsp_model.h"
+
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/stat.h>
+
+static VERBOSITY g_verbosity = NORMAL;
+
+static const char *const k_alg_names[12] = {
+    "Greedy", "Greedy Iterative", "2-opt Greedy", "Tabu Search", "VNS", "Cplex No SEC", "Cplex Benders Loop",
+    "Extra Mileage", "Cplex Benders Loop with Patching", "Cplex Branch&Cut", "Hard Fixing", "Local Branching"};
+static const char *const k_level_names[6] = {"TRACE", "DEBUG", "INFO", "WARN", "ERROR", "FATAL"};
+static const char *const k_level_colors[6] = {"\x1b[94m", "\x1b[36m", "\x1b[32m", "\x1b[33m", "\x1b[31m", "\x1b[35m"};
+
+bool err_ok(ERROR_CODE e) { return e == T_OK || e == CANCELLED || e == DEADLINE_EXCEEDED; }
+void err_setverbosity(VERBOSITY v) { g_verbosity = v; }
+bool err_dolog(void) { return g_verbosity >= VERBOSE; }
+
+/* visible levels: QUIET none; NORMAL warn+; VERBOSE info+; VERY_VERBOSE all (errors.c:47-62) */
+static bool level_visible(LOGGING_TYPE level)
+{
+    switch (g_verbosity) {
+    case QUIET: return false;
+    case NORMAL: return level >= LOG_WARN;
+    case VERBOSE: return level >= LOG_INFO;
+    default: return true;
+    }
+}
+
+void err_logging(LOGGING_TYPE level, const char *file, int line, const char *message, ...)
+{
+    if (!level_visible(level)) return;
+    char stamp[16];
+    time_t now = time(NULL);
+    stamp[strftime(stamp, sizeof stamp, "%H:%M:%S", localtime(&now))] = '\0';
+    fprintf(stderr, "%s %s%-5s\x1b[0m \x1b[90m%s:%d:\x1b[0m ", stamp, k_level_colors[level], k_level_names[level], file, line);
+    va_list ap;
+    va_start(ap, message);
+    vfprintf(stderr, message, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+}
+
+static void rule(void) { puts("--------------------------------------------------------------------------------\n"); }
+
+void err_setinfo(int alg, int nnodes, bool random, char *inputfile, double timelimit, int seed, int tabu_policy,
+                 int em, bool init_mip, int bc_policy, bool callback_relaxation, double lb_improv, int lb_delta,
+                 bool lb_kstar)
+{
+    (void)em; (void)init_mip; (void)bc_policy; (void)callback_relaxation; (void)lb_improv; (void)lb_delta; (void)lb_kstar;
+    if (g_verbosity == QUIET) return;
+    static const char *const pol[4] = {"Fixed", "Dependent on size", "Random", "Linear"};
+    puts("Travelling Salesman Problem Solver (MI355X 2-opt engine)");
+    rule();
+    printf("Algorithm:               %s\n", alg >= 0 && alg < 12 ? k_alg_names[alg] : "?");
+    printf("Number of nodes:         %d\n", nnodes);
+    printf("Random/File:             %s\n", random ? "random" : (inputfile ? inputfile : "?"));
+    if (timelimit != -1.0) printf("Timelimit:               %.2f\n", timelimit); else puts("Timelimit:               not set");
+    if (seed != -1) printf("Seed:                    %d\n", seed); else puts("Seed:                    not set");
+    if (alg == ALG_TABU_SEARCH) printf("Tenure Policy:           %s\n", pol[tabu_policy & 3]);
+    rule();
+}
+
+void err_printoutput(double cost, double time, int alg)
+{
+    if (g_verbosity != QUIET) {
+        rule();
+        printf("algorithm: %s\n", alg >= 0 && alg < 12 ? k_alg_names[alg] : "?");
+        printf("cost: %.2f\n", cost);
+        printf("execution time: %.2f seconds\n", time);
+        rule();
+        puts("Program finished, shutting down...");
+    } else if (alg == ALG_CX_BENDERS || alg == ALG_CX_BENDERS_PAT || alg == ALG_CX_BRANCH_AND_CUT) {
+        printf("Time: %.2f\n", time);   /* exact methods are compared on time (errors.c:158-160) */
+    } else {
+        printf("Cost: %.2f\n", cost);
+    }
+}
+
+void utils_safe_memory_free(void **p)
+{
+    if (p && *p) { free(*p); *p = NULL; }
+}
+
+bool utils_file_exists(const char *filename)
+{
+    struct stat st;
+    return stat(filename, &st) == 0;
+}
+
+void utils_startclock(struct timespec *c)
+{
+    if (clock_gettime(CLOCK_MONOTONIC, c) == -1) log_error("monotonic clock not supported");
+}
+
+double utils_timeelapsed(struct timespec *c)
+{
+    struct timespec now;
+    if (clock_gettime(CLOCK_MONOTONIC, &now) == -1) { log_error("monotonic clock not supported"); return -1.0; }
+    return (double)(now.tv_sec - c->tv_sec) + (double)(now.tv_nsec - c->tv_nsec) / 1e9;
+}
+
+void swap(int *a, int *b) { int t = *a; *a = *b; *b = t; }
+
+ERROR_CODE tsp_init_solution(int nnodes, tsp_solution *s)
+{
+    s->path = (int *)calloc((size_t)nnodes, sizeof(int));
+    s->comp = (int *)calloc((size_t)nnodes, sizeof(int));
+    s->cost = __DBL_MAX__;
+    s->ncomp = 0;
+    if (!s->path || !s->comp) { log_fatal("solution allocation failed"); return UNAVAILABLE; }
+    return T_OK;
+}
