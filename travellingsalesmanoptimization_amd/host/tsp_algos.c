@@ -234,7 +234,7 @@ ERROR_CODE tabu_dependent_policy(tabu_search *t)
 ERROR_CODE tabu_random_policy(tabu_search *t)
 {
     if (tsp_env.policy != POL_RANDOM) { log_warn("policy has already been set"); return ALREADY_EXISTS; }
-    t->tenure = (int)(rand() / RAND_MAX) * (t->max_tenure - t->min_tenure) + t->min_tenure;
+    t->tenure = (int)(tsp_rand() / RAND_MAX) * (t->max_tenure - t->min_tenure) + t->min_tenure;
     return T_OK;
 }
 
@@ -345,7 +345,7 @@ ERROR_CODE vns_kick(tsp_solution *solution)
     for (int i = 0; i < 3; i++) {
         int r;
         do {
-            r = rand() % n;
+            r = tsp_rand() % n;
             for (int j = 0; j < i; j++)
                 if (r == pick[j] || r == tour[pick[j] - 1] || r == tour[pick[j] + 1]) { r = -1; break; }
         } while (r == -1);
@@ -429,7 +429,7 @@ ERROR_CODE mh_VNS(void)
             memcpy(best.path, s.path, (size_t)n * sizeof(int));
         }
         if (f) fprintf(f, "%d,%f\n", it, s.cost);
-        const int kicks = rand() % (UPPER - LOWER + 1) - LOWER;
+        const int kicks = tsp_rand() % (UPPER - LOWER + 1) - LOWER;
         for (int j = 0; j < kicks; j++) vns_kick(&s);
     }
     if (f) fclose(f);

@@ -70,7 +70,7 @@ void tsp_init(void)
 /* tsp.c:468-481: glibc stream, x then y, node order */
 ERROR_CODE tsp_generate_randompoints(void)
 {
-    srand(tsp_env.seed);
+    tsp_srand((unsigned)tsp_env.seed);
     tsp_inst.points = (point *)calloc((size_t)tsp_inst.nnodes, sizeof(point));
     for (int i = 0; i < tsp_inst.nnodes; i++) {
         tsp_inst.points[i].x = TSP_RAND();

@@ -108,6 +108,39 @@ double utils_timeelapsed(struct timespec *c)
 
 void swap(int *a, int *b) { int t = *a; *a = *b; *b = t; }
 
+/* The program's own rand() stream.  The reference draws from glibc's process-wide generator
+ * (seed 1 unless -n seeds it: tsp.c:469); here the HIP runtime shares the process
+ * and consumes values from that generator while it initialises, so the host layer keeps the
+ * stream in a private TYPE_3 state (initstate(1, .., 128) == glibc's default table) and
+ * switches to it only around its own draws.  Same numbers as the reference binary sees. */
+static char g_rng_table[128];
+static bool g_rng_ready = false;
+
+static char *rng_enter(void)
+{
+    if (!g_rng_ready) {
+        char *prev = initstate(1u, g_rng_table, sizeof g_rng_table); /* leaves g_rng_table current */
+        g_rng_ready = true;
+        return prev;
+    }
+    return setstate(g_rng_table);
+}
+
+int tsp_rand(void)
+{
+    char *prev = rng_enter();
+    const int r = rand();
+    setstate(prev);
+    return r;
+}
+
+void tsp_srand(unsigned seed)
+{
+    char *prev = rng_enter();
+    srand(seed);
+    setstate(prev);
+}
+
 ERROR_CODE tsp_init_solution(int nnodes, tsp_solution *s)
 {
     s->path = (int *)calloc((size_t)nnodes, sizeof(int));

@@ -51,7 +51,9 @@ void err_setinfo(int alg, int nnodes, bool random, char *inputfile, double timel
 /* ---- src/utils/utils.h ---------------------------------------------------------- */
 #define MAX_COORDINATE 5000
 #define MIN_COORDINATE -5000
-#define TSP_RAND() (((double)rand() / RAND_MAX) * (MAX_COORDINATE - MIN_COORDINATE) + MIN_COORDINATE)
+#define TSP_RAND() (((double)tsp_rand() / RAND_MAX) * (MAX_COORDINATE - MIN_COORDINATE) + MIN_COORDINATE)
+int tsp_rand(void);            /* glibc rand() on the program's private stream (see tsp_log.c) */
+void tsp_srand(unsigned seed);
 #define NOT_CONNECTED -1.0f
 #define utils_safe_free(pointer) utils_safe_memory_free((void **)&(pointer))
 
