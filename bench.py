@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cpu-sweeps", type=int, default=150, help="bounded CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
     args = ap.parse_args()
 
     import torch
@@ -205,6 +206,35 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sweeps > 0:
         base = cpu_baseline(n, seed, args.cpu_sweeps)
 
+    # ---- the other matrix storage, same workload, for comparison (N = 1 only)
+    other = None
+    if rank == 0 and world == 1 and not args.no_other:
+        oelem = "f64" if args.elem == "i32" else "i32"
+        e2 = T.Engine(local)
+        e2.set_option(T.OPT_ELEM, T.ELEM_F64 if oelem == "f64" else T.ELEM_I32)
+        e2.set_option(T.OPT_BATCH, args.batch)
+        e2.set_points(xy); e2.build_costs(); e2.tour_nn(0, start); e2.tour_copy(1, 0)
+        e2.tour_copy(1, 0); e2.tour_two_opt(1)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sw2 = 0
+        for _ in range(args.steps):
+            e2.tour_copy(1, 0); sw2 += e2.tour_two_opt(1)[0]
+        dt2 = time.perf_counter() - t1
+        e2.set_option(T.OPT_TIMING, 1); e2.timing_read(reset=True)
+        e2.tour_copy(1, 0); e2.tour_two_opt(1)
+        ms2, l2 = e2.timing_read(reset=True)
+        e2.set_option(T.OPT_TIMING, 0)
+        bpe2 = 16 if oelem == "f64" else 8
+        k2 = ms2 / max(l2, 1)
+        _, c2, _ = e2.tour_store(1, want_path=False)
+        other = {"matrix_elem": oelem, "value": sw2 * evals / dt2, "unit": "evals/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                 "final_cost": c2, "kernel_ms_mean": k2, "bytes_per_eval": bpe2,
+                 "roofline_achieved_GBs": evals * bpe2 / (k2 * 1e-3) / 1e9,
+                 "roofline_frac": evals * bpe2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "traffic": load_traffic(f"n{n}_{oelem}")}
+        e2.close()
+
     if rank == 0:
         info = eng.info()
         out = {
@@ -228,7 +258,7 @@ def main():
             "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
             "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost,
             "matrix_build_ms": build_ms, "nn_tour_ms": nn_ms,
-            "roofline": roof, "cpu_baseline": base,
+            "roofline": roof, "cpu_baseline": base, "other_matrix_storage": other,
         }
         if base:
             out["gpu_over_cpu"] = out["value"] / base["value"]
