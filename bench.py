@@ -99,7 +99,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=123)
-    ap.add_argument("--elem", choices=["i32", "f64"], default=os.environ.get("TSPGPU_BENCH_ELEM", "i32"))
+    ap.add_argument("--elem", choices=["auto", "u16", "i32", "f64"], default=os.environ.get("TSPGPU_BENCH_ELEM", "auto"),
+                    help="matrix storage; auto = the engine's default (narrowest exact copy)")
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--wgs", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
@@ -126,7 +127,10 @@ def main():
     n, seed = args.n, args.seed
     evals = T.evals_per_sweep(n)
     eng = T.Engine(local)
-    eng.set_option(T.OPT_ELEM, T.ELEM_I32 if args.elem == "i32" else T.ELEM_F64)
+    ELEMS = {"auto": T.ELEM_AUTO, "u16": T.ELEM_U16, "i32": T.ELEM_I32, "f64": T.ELEM_F64}
+    NAMES = {T.ELEM_U16: "u16", T.ELEM_I32: "i32", T.ELEM_F64: "f64"}
+    BYTES = {T.ELEM_U16: 2, T.ELEM_I32: 4, T.ELEM_F64: 8}
+    eng.set_option(T.OPT_ELEM, ELEMS[args.elem])
     eng.set_option(T.OPT_KERNEL, args.kernel)
     eng.set_option(T.OPT_WGS_PER_TOUR, args.wgs)
     eng.set_option(T.OPT_BLOCK, args.block)
@@ -188,14 +192,14 @@ def main():
         ms_total, launches = eng.timing_read(reset=True)
         eng.set_option(T.OPT_TIMING, 0)
         info = eng.info()
-        bytes_per_eval = 8 if info["elem"] == T.ELEM_I32 else 16   # 2 matrix elements per eval
+        bytes_per_eval = 2 * BYTES[info["elem"]]                     # 2 matrix elements per eval
         kernel_ms = ms_total / max(launches, 1)
         achieved = evals * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
         back2back_ms = eng.time_sweep(1, 50)                         # 50 launches, no apply in between
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(f"n{n}_{args.elem}"),
-                "kernel": {1: "k_sweep_simple", 2: "k_sweep_pipe"}[info["kernel"]],
+                "traffic": load_traffic(f"n{n}_{NAMES[info['elem']]}"),
+                "kernel": {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res"}[info["kernel"]],
                 "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
                 "kernel_ms_back_to_back": back2back_ms,
                 "algorithmic_bytes_per_launch": evals * bytes_per_eval,
@@ -209,9 +213,9 @@ def main():
     # ---- the other matrix storage, same workload, for comparison (N = 1 only)
     other = None
     if rank == 0 and world == 1 and not args.no_other:
-        oelem = "f64" if args.elem == "i32" else "i32"
+        oelem = "f64" if eng.info()["elem"] != T.ELEM_F64 else "i32"   # the reference's own format, f64
         e2 = T.Engine(local)
-        e2.set_option(T.OPT_ELEM, T.ELEM_F64 if oelem == "f64" else T.ELEM_I32)
+        e2.set_option(T.OPT_ELEM, ELEMS[oelem])
         e2.set_option(T.OPT_BATCH, args.batch)
         e2.set_points(xy); e2.build_costs(); e2.tour_nn(0, start); e2.tour_copy(1, 0)
         e2.tour_copy(1, 0); e2.tour_two_opt(1)
@@ -244,14 +248,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * tmax / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32" if info["elem"] == T.ELEM_I32 else "f64",
+            "dtype": {T.ELEM_U16: "uint16 costs, int32 deltas", T.ELEM_I32: "int32", T.ELEM_F64: "f64"}[info["elem"]],
             "data": "synthetic",
             "config": {"workload": f"uniform-random EUC_2D n={n} (reference generator -n {n} -seed {seed}), "
                                    f"cost matrix resident in HBM, NN(start=rank) tour -> best-improvement 2-opt "
                                    f"to the local optimum; one step = one full local search",
                        "n": n, "seed": seed, "evals_per_sweep": evals,
                        "sweeps_per_step_rank0": my_sweeps // max(args.steps, 1),
-                       "matrix_elem": "int32 exact copy" if info["elem"] == T.ELEM_I32 else "f64",
+                       "matrix_elem": {T.ELEM_U16: "uint16 exact copy", T.ELEM_I32: "int32 exact copy", T.ELEM_F64: "f64"}[info["elem"]],
                        "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
                        "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
                        "parallelism": f"multistart-shard{world}"},

@@ -37,15 +37,16 @@ typedef struct tspgpu_ctx tspgpu_ctx;
  * definitions in double; the reference rejects them (src/tsp.c:576-584). */
 enum { TSPGPU_EUC_2D = 0, TSPGPU_ATT = 1, TSPGPU_CEIL_2D = 2 };
 
-/* storage of the device-resident cost matrix.  AUTO keeps an exact int32 copy
- * when every entry is an integer in [-1, 2^27) (true for every EUC_2D / ATT /
- * CEIL_2D matrix), else doubles. */
-enum { TSPGPU_ELEM_AUTO = 0, TSPGPU_ELEM_F64 = 1, TSPGPU_ELEM_I32 = 2 };
+/* storage of the device-resident cost matrix.  AUTO keeps the narrowest EXACT copy:
+ * uint16 when every entry is an integer in [0, 65534] (diagonal -1), int32 when every
+ * entry is an integer in [-1, 2^27) (true for every EUC_2D / ATT / CEIL_2D matrix),
+ * else doubles, the reference's own format. */
+enum { TSPGPU_ELEM_AUTO = 0, TSPGPU_ELEM_F64 = 1, TSPGPU_ELEM_I32 = 2, TSPGPU_ELEM_U16 = 3 };
 
 /* tunables (tspgpu_set_option) */
 enum {
     TSPGPU_OPT_ELEM = 1,        /* TSPGPU_ELEM_*; takes effect at the next build/set_costs */
-    TSPGPU_OPT_KERNEL = 2,      /* 0 auto, 1 force "simple" sweep, 2 force "pipelined" sweep */
+    TSPGPU_OPT_KERNEL = 2,      /* 0 auto, 1 "simple", 2 "pipelined", 3 "resident" sweep kernel */
     TSPGPU_OPT_BATCH = 3,       /* sweeps enqueued between host polls (default 32) */
     TSPGPU_OPT_WGS_PER_TOUR = 4,/* workgroups per tour in the sweep (0 = auto) */
     TSPGPU_OPT_HISTORY = 5,     /* record (a,b,delta) of the first N sweeps of slot 0 */

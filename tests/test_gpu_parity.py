@@ -31,6 +31,11 @@ def fx(O, v):
     return f"{O.fnv1a(v):016x}"
 
 
+# (matrix storage, sweep kernel): storage 1 f64, 2 int32, 3 uint16; kernel 1 simple, 2 pipelined,
+# 3 resident (the pipelined kernel has no uint16 variant)
+COMBOS = [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (3, 1), (3, 3)]
+
+
 def setup(eng, T, O, instances, name, elem, kernel=0):
     xy, c = instances(name)
     eng.set_option(T.OPT_ELEM, elem)
@@ -42,7 +47,7 @@ def setup(eng, T, O, instances, name, elem, kernel=0):
 
 # ------------------------------------------------------------------ K1 matrix
 @pytest.mark.parametrize("name", ["berlin52", "kroA100", "pr1002", "n1000_s123", "n64_s7"])
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2, 3])
 def test_matrix_bit_exact(eng, T, O, instances, name, elem):
     xy, c = instances(name)
     eng.set_option(T.OPT_ELEM, elem)
@@ -79,8 +84,15 @@ def test_set_costs_roundtrip_and_kind(eng, T, O, instances):
     _, c = instances("kroA100")
     eng.set_option(T.OPT_ELEM, 0)
     eng.set_costs(c)
-    assert eng.info()["elem"] == 2 and eng.info()["symmetric"] == 1  # integer-valued -> int32 copy
+    assert eng.info()["elem"] == 3 and eng.info()["symmetric"] == 1  # small integers -> uint16 copy
     assert np.array_equal(eng.get_costs(), c)
+    big = c.copy(); big[2, 7] = big[7, 2] = 70000.0
+    eng.set_costs(big)
+    assert eng.info()["elem"] == 2                                    # integers past 65534 -> int32 copy
+    assert np.array_equal(eng.get_costs(), big)
+    zd = c.copy(); np.fill_diagonal(zd, 0.0)
+    eng.set_costs(zd)
+    assert eng.info()["elem"] == 2 and np.array_equal(eng.get_costs(), zd)   # diagonal 0: not uint16
     f = c * 0.37
     eng.set_costs(f)
     assert eng.info()["elem"] == 1
@@ -92,7 +104,7 @@ def test_set_costs_roundtrip_and_kind(eng, T, O, instances):
 
 # ------------------------------------------------------------------ K6 NN
 @pytest.mark.parametrize("name", ["berlin52", "kroA100", "pr1002", "n1024_s1"])
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2, 3])
 def test_nn_tour(eng, T, O, instances, name, elem):
     xy, c = setup(eng, T, O, instances, name, elem)
     n = len(xy)
@@ -114,8 +126,7 @@ def test_nn_all_golden(eng, T, O, instances, golden):
 
 
 # ------------------------------------------------------------------ K2/K4 sweeps
-@pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem,kernel", COMBOS)
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "n64_s7", "n200_s3"])
 def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel):
     """every sweep picks the reference's (a,b) and leaves the reference's tour"""
@@ -131,8 +142,7 @@ def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel):
     assert eng.info()["kernel"] == kernel
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem,kernel", COMBOS)
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123", "n1024_s1"])
 def test_two_opt_to_local_optimum_golden(eng, T, O, instances, golden, name, elem, kernel):
     xy, c = setup(eng, T, O, instances, name, elem, kernel)
@@ -166,7 +176,7 @@ def test_first_moves_survey(eng, T, O, instances):
         eng.set_option(T.OPT_HISTORY, 0)
 
 
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem", [1, 2, 3])
 def test_full_size_fnl4461(eng, T, O, golden, elem):
     """BASELINE config 3: iterated 2-opt to the local optimum at n=4461 (603 sweeps; the
     reference needs 40 s on one core)"""
@@ -180,7 +190,7 @@ def test_full_size_fnl4461(eng, T, O, golden, elem):
     assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
 
 
-@pytest.mark.parametrize("elem,kernel", [(1, 0), (2, 0), (2, 1)])
+@pytest.mark.parametrize("elem,kernel", [(0, 0), (1, 0), (2, 0), (2, 1), (2, 3), (3, 0), (3, 1)])
 def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel):
     """the configuration BASELINE.json's metric is quoted on: -n 4096 -seed 123, NN(0) then
     609 sweeps to 488522 (reference: 48.7 s on one core)"""
@@ -261,8 +271,8 @@ def test_asymmetric_matrix_strict_orientation(eng, T, O):
     n = 96
     c = rng.integers(1, 1000, size=(n, n)).astype(np.float64)
     np.fill_diagonal(c, -1.0)
-    for elem in (1, 2):
-        for kernel in (1, 2):
+    for elem, kernel in [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3)]:
+        if True:
             eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel)
             eng.set_costs(c)
             assert eng.info()["symmetric"] == 0
@@ -345,8 +355,7 @@ def test_deadline_returns_code_4_with_valid_tour(eng, T, O, instances):
 
 
 # ------------------------------------------------------------------ K3 tabu
-@pytest.mark.parametrize("kernel", [1, 2])
-@pytest.mark.parametrize("elem", [1, 2])
+@pytest.mark.parametrize("elem,kernel", COMBOS)
 def test_tabu_move_golden(eng, T, O, instances, golden, elem, kernel):
     for case in golden["tabu_move"]:
         xy, c = setup(eng, T, O, instances, case["instance"], elem, kernel)

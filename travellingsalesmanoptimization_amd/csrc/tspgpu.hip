@@ -38,6 +38,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -64,25 +65,42 @@ struct Partial {
 // element traits: the matrix is held either as doubles (any caller matrix) or
 // as an exact int32 copy (every integer-valued matrix: EUC_2D, ATT, CEIL_2D)
 // ---------------------------------------------------------------------------
+typedef unsigned short u16;
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef u16 v8u16 __attribute__((ext_vector_type(8)));
 
+// T = storage type of a matrix cell, acc = the type deltas are computed in.
+// uint16 cells hold exact integer costs 0..65534; 65535 is the diagonal (-1 in the reference).
 template <typename T> struct Elem;
 template <> struct Elem<double> {
     typedef v2f64 vec;
+    typedef double acc;
     static constexpr int V = 2;
     __device__ static double lim() { return DBL_MAX; }
     __device__ static double big() { return 1.0e300; }   // poison: above any real delta, sums stay finite
+    __device__ static double widen(double x) { return x; }
 };
 template <> struct Elem<int> {
     typedef v4i32 vec;
+    typedef int acc;
     static constexpr int V = 4;
     __device__ static int lim() { return INT_MAX; }
     __device__ static int big() { return 1 << 29; }      // poison; real costs < 2^27 so |delta| < 2^28
+    __device__ static double widen(int x) { return (double)x; }
+};
+template <> struct Elem<u16> {
+    typedef v8u16 vec;
+    typedef int acc;
+    static constexpr int V = 8;
+    __device__ static int lim() { return INT_MAX; }
+    __device__ static int big() { return 1 << 29; }
+    __device__ static double widen(u16 x) { return x == 0xFFFFu ? -1.0 : (double)x; }
 };
 
 __device__ __forceinline__ double vget(const v2f64 &v, int i) { return v[i]; }
 __device__ __forceinline__ int vget(const v4i32 &v, int i) { return v[i]; }
+__device__ __forceinline__ int vget(const v8u16 &v, int i) { return (int)v[i]; }
 
 __device__ __forceinline__ bool key_better(double d1, u64 k1, double d2, u64 k2)
 {
@@ -159,7 +177,8 @@ __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__
 }
 
 // ingest of a caller matrix: flags[0] = some entry is not an int in [-1, 2^27),
-// flags[1] = some c[i][j] != c[j][i]
+// flags[1] = some c[i][j] != c[j][i], flags[2] = not representable as uint16 cells
+// (off-diagonal integer in [0, 65534], diagonal exactly -1)
 __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, int n, int ld, int *flags)
 {
     const int i = blockIdx.y;
@@ -169,22 +188,25 @@ __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, i
     const double r = __builtin_trunc(x);
     if (!(r == x && x >= -1.0 && x < 134217728.0)) flags[0] = 1;
     if (j > i && m[(size_t)j * ld + i] != x) flags[1] = 1;
+    if (i == j ? x != -1.0 : !(r == x && x >= 0.0 && x <= 65534.0)) flags[2] = 1;
 }
 
-__global__ void __launch_bounds__(256) k_f64_to_i32(const double *__restrict__ m, int n, int ld, int *__restrict__ out)
+template <typename TD>
+__global__ void __launch_bounds__(256) k_from_f64(const double *__restrict__ m, int n, int ld, TD *__restrict__ out)
 {
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ld) return;
-    out[(size_t)i * ld + j] = j < n ? (int)m[(size_t)i * ld + j] : 0;
+    out[(size_t)i * ld + j] = j < n ? (TD)(int)m[(size_t)i * ld + j] : (TD)0; // -1 -> 0xFFFF for uint16
 }
 
-__global__ void __launch_bounds__(256) k_i32_to_f64(const int *__restrict__ m, int n, int ld, double *__restrict__ out)
+template <typename TS>
+__global__ void __launch_bounds__(256) k_to_f64(const TS *__restrict__ m, int n, int ld, double *__restrict__ out)
 {
     const int i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= ld) return;
-    out[(size_t)i * ld + j] = j < n ? (double)m[(size_t)i * ld + j] : 0.0;
+    out[(size_t)i * ld + j] = j < n ? Elem<TS>::widen(m[(size_t)i * ld + j]) : 0.0;
 }
 
 // ---------------------------------------------------------------------------
@@ -237,19 +259,20 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
                                                     const int *__restrict__ caps)
 {
     __shared__ double chunk[1024];
+    typedef typename Elem<T>::acc AT;
     const int t = slot0 + blockIdx.x;
     const int *ord = S.ord + (size_t)t * n;
     int *pos = S.pos + (size_t)t * n;
-    T *dp = dpos_of<T>(S, t, n);
+    AT *dp = dpos_of<AT>(S, t, n);
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
         const int node = ord[p];
         const int s = ord[p + 1 == n ? 0 : p + 1];
         pos[node] = p;
-        dp[p] = mat[(size_t)node * ld + s];
+        dp[p] = (AT)mat[(size_t)node * ld + s];
     }
     __syncthreads();
     double total = 0;
-    if constexpr (sizeof(T) == 4) {
+    if constexpr (std::is_same<AT, int>::value) {
         long long part = 0;
         for (int i = threadIdx.x; i < n; i += blockDim.x) part += dp[i];
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
@@ -320,7 +343,7 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
         u64 arg = KEY_NONE;
         for (int k = 0, i = tid; i < n; i += BT, k++) {
             if ((seen >> k) & 1) continue;
-            const double w = (double)row[i];
+            const double w = Elem<T>::widen(row[i]);
             if (w != -1.0 && w < lo) { lo = w; arg = (u64)i; } // NOT_CONNECTED, utils.h:35
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -341,7 +364,7 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
         cur = nxt;
     }
     if (tid == 0) {
-        total += (double)mat[(size_t)cur * ld + start]; // heuristics.c:281
+        total += Elem<T>::widen(mat[(size_t)cur * ld + start]); // heuristics.c:281
         S.cost[t] = total;
         S.status[t] = (step == n) ? 0 : 1; // 1: tour left incomplete
     }
@@ -413,13 +436,14 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
     const int *pos = A.S.pos + (size_t)t * n;
-    const T *dp = dpos_of<T>(A.S, t, n);
+    typedef typename Elem<T>::acc AT;
+    const AT *dp = dpos_of<AT>(A.S, t, n);
     const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
 
-    T best_d = TABU ? Elem<T>::lim() : (T)0;
+    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
     u64 best_key = TABU ? KEY_NONE : 0; // key 0 cannot be beaten on a tie: "no move" is (0, 0)
 
     const int p0 = blockIdx.x * A.P;
@@ -438,7 +462,7 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
         if constexpr (TABU) {
             if (is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure)) continue;
         }
-        const T d_a = dp[p];
+        const AT d_a = dp[p];
         const T *rowA = mat + (size_t)a * ld;
         const int kmax = A.symmetric ? n / 2 : n - 1 - a;
         for (int k = 1 + tid; k <= kmax; k += BT) {
@@ -451,9 +475,9 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
             if constexpr (TABU) {
                 if (is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure)) continue;
             }
-            const T made = rowA[b] + rowS[sb];                      // c[a][b] + c[sa][sb]
-            const T kept = d_a + dp[dir > 0 ? q : wrap(q - 1, n)];  // c[a][sa] + c[b][sb]
-            consider<T>(made - kept, a, b, best_d, best_key);
+            const AT made = (AT)rowA[b] + (AT)rowS[sb];              // c[a][b] + c[sa][sb]
+            const AT kept = d_a + dp[dir > 0 ? q : wrap(q - 1, n)];  // c[a][sa] + c[b][sb]
+            consider<AT>(made - kept, a, b, best_d, best_key);
         }
     }
     double d = (double)best_d;
@@ -699,6 +723,178 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 
 
 // ---------------------------------------------------------------------------
+// K2/K3 "resident" sweep: for rows small enough that the P+1 (<= 9) rows of a run fit LDS
+// together (uint16 cells up to n ~ 9 000 at one workgroup per CU, int32 / f64 for small n
+// and for multi-start batches).  The workgroup fetches all its rows at once (every load in
+// flight together: one memory round trip for the whole run), lands them, and after ONE
+// barrier each wave walks the run's steps on its own -- no barrier, no LDS write and no
+// global access inside the step loop.  The three pairs refinment.c:55 skips are masked
+// from registers: a thread knows, for each of its own b's, which step index j (if any) has
+// b as its node a_j, and pair (a_s, b) is invalid exactly when |s - j| <= 1.
+// Same pair ownership, argmin key and arithmetic as k_sweep_pipe.
+// ---------------------------------------------------------------------------
+template <typename T, int NCH, int PMAX, bool TABU>
+__global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
+{
+    typedef typename Elem<T>::vec VT;
+    typedef typename Elem<T>::acc AT;
+    constexpr int V = Elem<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = A.n, ld = A.ld;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V;
+
+    // LDS: (P+1) rows | nodes[-1 .. P] | reduction scratch
+    T *rows = reinterpret_cast<T *>(smem);
+    const size_t rows_bytes = (size_t)(A.P + 1) * ld * sizeof(T);
+    int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
+    Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4);
+
+    const T *mat = static_cast<const T *>(A.mat);
+    const int *ord = A.S.ord + (size_t)t * n;
+    const int *pos = A.S.pos + (size_t)t * n;
+    const AT *dp = dpos_of<AT>(A.S, t, n);
+    const int dir = A.S.dir[t];
+
+    int iter = 0, tenure = 0;
+    if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
+
+    const int p0 = blockIdx.x * A.P;
+    const int cnt = min(A.P, n - p0);
+    // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
+    for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+
+    int q[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            q[c][v] = b < n ? pos[b] : 0;
+        }
+    __syncthreads(); // nodes[] visible
+
+    // every row of the run in flight at once
+    VT R[PMAX + 1][NCH];
+#pragma unroll
+    for (int r = 0; r <= PMAX; r++) {
+        if (r <= cnt && A.ablate != 2) {
+            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[r] * ld);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) R[r][c] = src[min(c * BT + tid, nvec - 1)];
+        }
+    }
+
+    // per-thread state of the owned b's (loads that depend on pos[b], issued behind the rows)
+    const AT BIG = Elem<T>::big();
+    int sboff[NCH][V], jb[NCH][V];
+    AT dnv[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            const int sb = ord[wrap(q[c][v] + dir, n)];
+            const AT dn = dp[dir > 0 ? q[c][v] : wrap(q[c][v] - 1, n)];
+            bool sk = b >= n;
+            if constexpr (TABU)
+                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
+            sboff[c][v] = sb * (int)sizeof(T);
+            dnv[c][v] = sk ? -BIG : dn;      // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+            // step index whose node a_j is b (run positions p0 .. p0+cnt, walked along dir), else far away
+            int j = dir > 0 ? q[c][v] - p0 : p0 + cnt - q[c][v];
+            if (j < -1) j += n;              // the run may wrap past position n-1 / below 0
+            if (j > n - 2) j -= n;
+            jb[c][v] = (b < n && j >= -1 && j <= cnt) ? j : 1 << 20;
+        }
+
+#pragma unroll
+    for (int r = 0; r <= PMAX; r++) {
+        if (r <= cnt && A.ablate != 2) {
+            VT *dst = reinterpret_cast<VT *>(rows + (size_t)r * ld);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[r][c];
+        }
+    }
+    __syncthreads(); // the only barrier in front of the step loop
+
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
+    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
+    bool have = false;
+
+    for (int s = 0; s < cnt; s++) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const T *bA = rows + (size_t)s * ld;
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
+        bool live = A.ablate != 1;
+        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        if (!live) continue;
+        const AT d_a = (AT)bA[sa];            // c[a][succ a]
+        // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
+        const int lo = a + 1 == n ? 0 : a + 1;
+        const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
+            if (w0 >= n) continue;                          // pad wave
+            int t0 = w0 - lo;
+            if (t0 < 0) t0 += n;
+            const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
+            const bool inside = nowrap && t0 + 64 * V <= len;
+            if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
+            const int b0 = (c * BT + tid) * V;
+            const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
+            AT g[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const int b = b0 + v;
+                AT delta;
+                if constexpr (std::is_same<AT, int>::value) delta = (AT)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
+                else { const AT made = (AT)vget(xa, v) + g[v]; const AT kept = d_a + dnv[c][v]; delta = made - kept; } // refinment.c:58-60
+                bool ok = (unsigned)(s - jb[c][v] + 1) > 2u;   // not b in {pred a, a, succ a}
+                if (!inside) {
+                    int tt = b - lo;
+                    tt += (tt >> 31) & n;
+                    ok &= (unsigned)tt < (unsigned)len;
+                }
+                const bool lt = ok & (delta < best_d);
+                bool eq = ok & (delta == best_d);
+                if constexpr (!TABU) eq &= delta < (AT)0;
+                if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                    if (eq) {
+                        const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                        const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                       : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                        if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                    }
+                }
+                best_d = lt ? delta : best_d;
+                best_a = lt ? a : best_a;
+                best_b = lt ? b : best_b;
+                have = have | lt;
+            }
+        }
+    }
+
+    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
+    double d = (double)best_d;
+    u64 key;
+    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // K4 apply: one workgroup per tour.  Reduces the per-workgroup partials to the
 // global (delta, a, b) and applies the move (see the Tours comment): reverse the
 // shorter arc in ord/pos/dpos, toggle dir when that arc is not ref_reverse_path's
@@ -742,8 +938,9 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
     const bool move = TABU ? (key != KEY_NONE) : (d < TWO_OPT_EPS);
     const int a = (int)(key >> 32), b = (int)(key & 0xffffffffu);
 
+    typedef typename Elem<T>::acc AT;
     int *ord = A.S.ord + (size_t)t * n, *pos = A.S.pos + (size_t)t * n;
-    T *dp = dpos_of<T>(A.S, t, n);
+    AT *dp = dpos_of<AT>(A.S, t, n);
     const int dir = A.S.dir[t];
     int ndir = dir; // direction after this move
     int sa = -1, sb = -1;
@@ -774,17 +971,17 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
         if (A.symmetric) {
             for (int k = tid; k < (M - 1) / 2; k += BT) {
                 const int pe = wrap(lo + k, n), qe = wrap(lo + M - 2 - k, n);
-                const T eu = dp[pe], ev = dp[qe];
+                const AT eu = dp[pe], ev = dp[qe];
                 dp[pe] = ev; dp[qe] = eu;
             }
-            if (tid == 0) dp[wrap(lo - 1, n)] = mat[(size_t)x0 * ld + x2];
-            if (tid == 64 % BT) dp[wrap(lo + M - 1, n)] = mat[(size_t)x1 * ld + x3];
+            if (tid == 0) dp[wrap(lo - 1, n)] = (AT)mat[(size_t)x0 * ld + x2];
+            if (tid == 64 % BT) dp[wrap(lo + M - 1, n)] = (AT)mat[(size_t)x1 * ld + x3];
         } else {
             __syncthreads(); // cells final; re-read the costs of edges lo-1 .. lo+M-1 in tour direction
             for (int k = tid; k <= M; k += BT) {
                 const int pe = wrap(lo - 1 + k, n);
                 const int un = ord[pe], vn = ord[wrap(pe + 1, n)];
-                dp[pe] = dir > 0 ? mat[(size_t)un * ld + vn] : mat[(size_t)vn * ld + un];
+                dp[pe] = (AT)(dir > 0 ? mat[(size_t)un * ld + vn] : mat[(size_t)vn * ld + un]);
             }
         }
         if (other) { ndir = -dir; if (tid == 0) A.S.dir[t] = ndir; }
@@ -869,10 +1066,10 @@ struct tspgpu_ctx {
     // instance
     int n = 0, ld = 0, kind = TSPGPU_EUC_2D;
     bool have_points = false, have_costs = false, symmetric = true;
-    int elem = 0; // TSPGPU_ELEM_F64 / _I32 in use
+    int elem = 0; // TSPGPU_ELEM_F64 / _I32 / _U16 in use
     double2 *d_pts = nullptr;
-    double *d_f64 = nullptr; // [n][ld], present when elem == F64 (or transiently)
-    int *d_i32 = nullptr;    // [n][ld], present when elem == I32
+    void *d_mat = nullptr;   // [n][ld] cells of the kind in `elem`
+    double cost_bound = 0;   // upper bound of any entry the uploaded points can produce
     int *d_flags = nullptr;
 
     // tours
@@ -926,9 +1123,8 @@ static void drop_graphs(tspgpu_ctx *ctx)
 
 static void free_matrix(tspgpu_ctx *ctx)
 {
-    if (ctx->d_f64) hipFree(ctx->d_f64);
-    if (ctx->d_i32) hipFree(ctx->d_i32);
-    ctx->d_f64 = nullptr; ctx->d_i32 = nullptr; ctx->have_costs = false;
+    if (ctx->d_mat) hipFree(ctx->d_mat);
+    ctx->d_mat = nullptr; ctx->have_costs = false;
     drop_graphs(ctx);
 }
 
@@ -996,9 +1192,15 @@ static int new_instance(tspgpu_ctx *ctx, int n)
     return E_OK;
 }
 
-template <typename T> static const T *mat_of(const tspgpu_ctx *ctx);
-template <> const double *mat_of<double>(const tspgpu_ctx *ctx) { return ctx->d_f64; }
-template <> const int *mat_of<int>(const tspgpu_ctx *ctx) { return ctx->d_i32; }
+static size_t elem_size(int elem) { return elem == TSPGPU_ELEM_F64 ? 8 : elem == TSPGPU_ELEM_I32 ? 4 : 2; }
+
+// run `...` with T bound to the storage type of `elem`
+#define ELEM_SWITCH(elem, T, ...)                                             \
+    do {                                                                      \
+        if ((elem) == TSPGPU_ELEM_F64) { typedef double T; __VA_ARGS__; }     \
+        else if ((elem) == TSPGPU_ELEM_I32) { typedef int T; __VA_ARGS__; }   \
+        else { typedef u16 T; __VA_ARGS__; }                                  \
+    } while (0)
 
 // --------------------------------------------------------------- launch plan
 template <typename T, int NCH, int D, bool TABU> static const void *pipe_fn() { return (const void *)k_sweep_pipe<T, NCH, D, TABU>; }
@@ -1031,10 +1233,20 @@ static const void *pipe_kernel(int elem, int nch, int depth, bool tabu)
     return nullptr;
 }
 
+template <typename T, int NCH, bool TABU> static const void *res_fn() { return (const void *)k_sweep_res<T, NCH, 8, TABU>; }
+static const void *res_kernel(int elem, int nch, bool tabu)
+{
+    const void *fn = nullptr;
+    ELEM_SWITCH(elem, T, fn = nch == 1 ? (tabu ? res_fn<T, 1, true>() : res_fn<T, 1, false>())
+                                       : (tabu ? res_fn<T, 2, true>() : res_fn<T, 2, false>()));
+    return fn;
+}
+
 static const void *simple_kernel(int elem, bool tabu)
 {
-    if (elem == TSPGPU_ELEM_F64) return tabu ? (const void *)k_sweep_simple<double, true> : (const void *)k_sweep_simple<double, false>;
-    return tabu ? (const void *)k_sweep_simple<int, true> : (const void *)k_sweep_simple<int, false>;
+    const void *fn = nullptr;
+    ELEM_SWITCH(elem, T, fn = tabu ? (const void *)k_sweep_simple<T, true> : (const void *)k_sweep_simple<T, false>);
+    return fn;
 }
 
 static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
@@ -1043,7 +1255,7 @@ static int pow2_ceil(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 static int make_plan(tspgpu_ctx *ctx, int ntours)
 {
     const int n = ctx->n, ld = ctx->ld;
-    const size_t esz = ctx->elem == TSPGPU_ELEM_F64 ? 8 : 4;
+    const size_t esz = elem_size(ctx->elem);
     const int V = 16 / (int)esz;
     const int nvec = ld / V;
     const size_t row = (size_t)ld * esz;
@@ -1074,7 +1286,36 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         G = (n + P - 1) / P;
     };
     int G = 1, P = n;
-    if (kernel == 0) kernel = pipe_fits(BT, 64) ? 2 : 1;
+    if (ctx->elem == TSPGPU_ELEM_U16 && kernel == 2) return fail(ctx, E_INVALID, "the pipelined sweep has no uint16 variant");
+    // resident sweep: all P+1 (<= 9) rows of a run in LDS at once.  One chunk per thread for
+    // uint16 (two would spill), at most two otherwise.
+    const int res_bt = std::min(1024, std::max(64, pow2_ceil(nvec)));
+    const int res_nch = (nvec + res_bt - 1) / res_bt;
+    auto res_P = [&]() { // rows that fit: prefer two workgroups per CU when that still gives P = 8
+        const size_t extra = slack + 64;
+        if (9 * row + extra <= ctx->lds_max / 2) return 8;
+        const long fit = (long)((ctx->lds_max - extra) / row) - 1;
+        return (int)std::min<long>(8, fit);
+    };
+    const bool res_ok = res_nch <= (ctx->elem == TSPGPU_ELEM_U16 ? 1 : 2) && res_P() >= 2 && n >= 8;
+    if (kernel == 3 && !res_ok) return fail(ctx, E_EXHAUSTED, "resident sweep: rows of %zu B do not fit", row);
+    if (kernel == 0) {
+        // uint16: resident whenever it fits.  int32 / f64: resident only while 9 rows leave room
+        // for two workgroups per CU (small n, multi-start batches); else pipelined; else simple.
+        if (res_ok && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
+        else kernel = (pipe_fits(BT, 64) && ctx->elem != TSPGPU_ELEM_U16) ? 2 : 1;
+    }
+    if (kernel == 3) {
+        BT = ctx->opt_block > 0 ? BT : res_bt;
+        nch = (nvec + BT - 1) / BT;
+        if (nch > (ctx->elem == TSPGPU_ELEM_U16 ? 1 : 2)) { BT = res_bt; nch = res_nch; }
+        P = res_P();
+        if (ctx->opt_wgs > 0) P = std::max(2, std::min(P, (n + ctx->opt_wgs - 1) / ctx->opt_wgs));
+        G = (n + P - 1) / P;
+        if (G > MAX_WGS_PER_TOUR) return fail(ctx, E_EXHAUSTED, "resident sweep: %d workgroups per tour exceed %d", G, MAX_WGS_PER_TOUR);
+        ctx->plan_D = 0;
+        ctx->plan_lds = (size_t)(P + 1) * row + (size_t)((P + 2 + 3) & ~3) * 4 + 16 * sizeof(Partial) + 64;
+    }
     if (kernel == 2) {
         nch = (nvec + BT - 1) / BT;
         while (nch > 4 && BT < 1024) { BT *= 2; nch = (nvec + BT - 1) / BT; }
@@ -1105,7 +1346,8 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
     // raise the dynamic-LDS cap of the kernels we are going to launch
     for (int tabu = 0; tabu < 2; tabu++) {
-        const void *fn = kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
+        const void *fn = kernel == 3 ? res_kernel(ctx->elem, nch, tabu)
+                       : kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
         if (!fn) return fail(ctx, E_INTERNAL, "no kernel instance for nch=%d", nch);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
     }
@@ -1116,13 +1358,14 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
 {
     SweepArgs A;
     A.S = ctx->S;
-    A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
+    A.mat = ctx->d_mat;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.P = ctx->plan_P;
     A.symmetric = ctx->symmetric ? 1 : 0;
     A.ablate = ctx->opt_ablate;
     A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
-    const void *fn = ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
+    const void *fn = ctx->plan_kernel == 3 ? res_kernel(ctx->elem, ctx->plan_NCH, tabu)
+                   : ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
     void *args[] = {&A};
     HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
     return E_OK;
@@ -1132,16 +1375,15 @@ static int launch_apply(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, bool 
 {
     ApplyArgs A;
     A.S = ctx->S;
-    A.mat = ctx->elem == TSPGPU_ELEM_F64 ? (const void *)ctx->d_f64 : (const void *)ctx->d_i32;
+    A.mat = ctx->d_mat;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.G = ctx->plan_G;
     A.symmetric = ctx->symmetric ? 1 : 0;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
     A.best_succ = ctx->d_best_succ; A.trace = resident_tabu ? ctx->d_trace : nullptr;
     A.hist = ctx->hist;
     const int BT = std::min(1024, std::max(64, pow2_ceil(ctx->n / 4)));
-    const void *fn;
-    if (ctx->elem == TSPGPU_ELEM_F64) fn = tabu ? (const void *)k_apply<double, true> : (const void *)k_apply<double, false>;
-    else fn = tabu ? (const void *)k_apply<int, true> : (const void *)k_apply<int, false>;
+    const void *fn = nullptr;
+    ELEM_SWITCH(ctx->elem, T, fn = tabu ? (const void *)k_apply<T, true> : (const void *)k_apply<T, false>);
     void *args[] = {&A};
     HIP_TRY(hipLaunchKernel(fn, dim3(ntours), dim3(BT), args, 0, ctx->stream));
     return E_OK;
@@ -1253,10 +1495,8 @@ static int init_slots(tspgpu_ctx *ctx, int slot0, int ntours, int cap)
         caps = ctx->d_caps;
     }
     const int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
-    if (ctx->elem == TSPGPU_ELEM_F64)
-        hipLaunchKernelGGL((k_tour_init<double>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_f64, n, ctx->ld, slot0, caps);
-    else
-        hipLaunchKernelGGL((k_tour_init<int>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_i32, n, ctx->ld, slot0, caps);
+    ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_tour_init<T>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S,
+                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, caps));
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
@@ -1303,10 +1543,8 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
     int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
     while ((long)BT * 64 < n) BT *= 2; // register visited mask: n <= 64*BT
     if (BT > 1024) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 65536");
-    if (ctx->elem == TSPGPU_ELEM_F64)
-        hipLaunchKernelGGL((k_nn<double>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_f64, n, ctx->ld, slot0, ctx->d_starts);
-    else
-        hipLaunchKernelGGL((k_nn<int>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S, ctx->d_i32, n, ctx->ld, slot0, ctx->d_starts);
+    ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
+                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts));
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
@@ -1374,8 +1612,8 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     if (!ctx) return E_INVALID;
     hipSetDevice(ctx->device);
     switch (option) {
-    case TSPGPU_OPT_ELEM: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad element kind"); ctx->opt_elem = (int)value; break;
-    case TSPGPU_OPT_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad kernel id"); ctx->opt_kernel = (int)value; ctx->plan_kernel = 0; break;
+    case TSPGPU_OPT_ELEM: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad element kind"); ctx->opt_elem = (int)value; break;
+    case TSPGPU_OPT_KERNEL: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad kernel id"); ctx->opt_kernel = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_BATCH: if (value < 1 || value > 4096) return fail(ctx, E_INVALID, "bad batch"); ctx->opt_batch = (int)value; drop_graphs(ctx); break;
     case TSPGPU_OPT_WGS_PER_TOUR: if (value < 0 || value > MAX_WGS_PER_TOUR) return fail(ctx, E_INVALID, "bad wgs"); ctx->opt_wgs = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_HISTORY: {
@@ -1436,19 +1674,24 @@ int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_
     HIP_TRY(hipMemcpy(ctx->d_pts, xy, (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
     ctx->kind = edge_weight_type;
     ctx->have_points = true;
+    double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
+    for (int i = 1; i < n; i++) {
+        x0 = std::min(x0, xy[2 * i]); x1 = std::max(x1, xy[2 * i]);
+        y0 = std::min(y0, xy[2 * i + 1]); y1 = std::max(y1, xy[2 * i + 1]);
+    }
+    const double diag = std::sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
+    ctx->cost_bound = (edge_weight_type == TSPGPU_ATT ? diag / std::sqrt(10.0) : diag) + 2.0;
     return E_OK;
 }
 
 static int launch_build(tspgpu_ctx *ctx)
 {
     const int n = ctx->n, ld = ctx->ld;
-    if (ctx->elem == TSPGPU_ELEM_F64) {
-        dim3 grid((ld / 2 + 255) / 256, n);
-        hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, ctx->d_f64);
-    } else {
-        dim3 grid((ld / 4 + 255) / 256, n);
-        hipLaunchKernelGGL((k_build_costs<int>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, ctx->d_i32);
-    }
+    ELEM_SWITCH(ctx->elem, T, {
+        constexpr int V = 16 / (int)sizeof(T);
+        dim3 grid((ld / V + 255) / 256, n);
+        hipLaunchKernelGGL((k_build_costs<T>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (T *)ctx->d_mat);
+    });
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
@@ -1460,10 +1703,14 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
     if (!ctx->have_points) return fail(ctx, E_PRECOND, "no points: call tspgpu_set_points first");
     free_matrix(ctx);
     const size_t cells = (size_t)ctx->n * ctx->ld;
-    // every supported edge-weight kind yields integers, so AUTO means int32
-    ctx->elem = ctx->opt_elem == TSPGPU_ELEM_F64 ? TSPGPU_ELEM_F64 : TSPGPU_ELEM_I32;
-    if (ctx->elem == TSPGPU_ELEM_F64) HIP_TRY(hipMalloc(&ctx->d_f64, cells * 8));
-    else HIP_TRY(hipMalloc(&ctx->d_i32, cells * 4));
+    // every supported edge-weight kind yields integers: AUTO = the narrowest exact storage.
+    // cost_bound (from the bounding box of the points) decides whether 16 bits are enough.
+    const bool fits16 = ctx->cost_bound <= 65534.0, fits32 = ctx->cost_bound < 134217728.0;
+    if (ctx->opt_elem == TSPGPU_ELEM_U16 && !fits16) return fail(ctx, E_INVALID, "uint16 storage requested but costs may reach %.0f", ctx->cost_bound);
+    if (ctx->opt_elem == TSPGPU_ELEM_I32 && !fits32) return fail(ctx, E_INVALID, "int32 storage requested but costs may reach %.0f", ctx->cost_bound);
+    if (ctx->opt_elem != TSPGPU_ELEM_AUTO) ctx->elem = ctx->opt_elem;
+    else ctx->elem = fits16 ? TSPGPU_ELEM_U16 : fits32 ? TSPGPU_ELEM_I32 : TSPGPU_ELEM_F64;
+    HIP_TRY(hipMalloc(&ctx->d_mat, cells * elem_size(ctx->elem)));
     int rc = launch_build(ctx);
     if (rc) return rc;
     ctx->symmetric = true; // Euclidean
@@ -1486,28 +1733,35 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
     }
     const int ld = ctx->ld;
     const size_t cells = (size_t)n * ld;
-    HIP_TRY(hipMalloc(&ctx->d_f64, cells * 8));
-    HIP_TRY(hipMemsetAsync(ctx->d_f64, 0, cells * 8, ctx->stream));
-    HIP_TRY(hipMemcpy2DAsync(ctx->d_f64, (size_t)ld * 8, host_costs, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(k_inspect, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_f64, n, ld, ctx->d_flags);
+    double *stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, cells * 8));
+    HIP_TRY(hipMemsetAsync(stage, 0, cells * 8, ctx->stream));
+    HIP_TRY(hipMemcpy2DAsync(stage, (size_t)ld * 8, host_costs, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->stream));
+    hipLaunchKernelGGL(k_inspect, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, stage, n, ld, ctx->d_flags);
     HIP_TRY(hipGetLastError());
-    int flags[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 8, hipMemcpyDeviceToHost, ctx->stream));
+    int flags[3] = {0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 12, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const bool integral = flags[0] == 0;
+    const bool integral = flags[0] == 0, fits16 = flags[2] == 0;
     ctx->symmetric = flags[1] == 0;
-    if (ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) {
-        free_matrix(ctx);
-        return fail(ctx, E_INVALID, "int32 storage requested but the matrix is not integer-valued in [-1, 2^27)");
+    if ((ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) || (ctx->opt_elem == TSPGPU_ELEM_U16 && !fits16)) {
+        hipFree(stage);
+        return fail(ctx, E_INVALID, "integer storage requested but the matrix is not representable (int32: integers in [-1, 2^27); uint16: integers in [0, 65534] with a -1 diagonal)");
     }
-    ctx->elem = (ctx->opt_elem == TSPGPU_ELEM_F64 || !integral) ? TSPGPU_ELEM_F64 : TSPGPU_ELEM_I32;
-    if (ctx->elem == TSPGPU_ELEM_I32) {
-        HIP_TRY(hipMalloc(&ctx->d_i32, cells * 4));
-        hipLaunchKernelGGL(k_f64_to_i32, dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_f64, n, ld, ctx->d_i32);
+    if (ctx->opt_elem != TSPGPU_ELEM_AUTO) ctx->elem = ctx->opt_elem;
+    else ctx->elem = fits16 ? TSPGPU_ELEM_U16 : integral ? TSPGPU_ELEM_I32 : TSPGPU_ELEM_F64;
+    if (ctx->elem == TSPGPU_ELEM_F64) {
+        ctx->d_mat = stage;
+    } else {
+        HIP_TRY(hipMalloc(&ctx->d_mat, cells * elem_size(ctx->elem)));
+        if (ctx->elem == TSPGPU_ELEM_I32)
+            hipLaunchKernelGGL((k_from_f64<int>), dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, stage, n, ld, (int *)ctx->d_mat);
+        else
+            hipLaunchKernelGGL((k_from_f64<u16>), dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, stage, n, ld, (u16 *)ctx->d_mat);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        hipFree(ctx->d_f64); ctx->d_f64 = nullptr;
+        hipFree(stage);
     }
     ctx->have_costs = true;
     ctx->plan_kernel = 0;
@@ -1521,11 +1775,14 @@ int tspgpu_get_costs(tspgpu_ctx *ctx, double *host_out)
     int rc = need_costs(ctx);
     if (rc) return rc;
     const int n = ctx->n, ld = ctx->ld;
-    const double *src = ctx->d_f64;
+    const double *src = (const double *)ctx->d_mat;
     double *tmp = nullptr;
-    if (ctx->elem == TSPGPU_ELEM_I32) {
+    if (ctx->elem != TSPGPU_ELEM_F64) {
         HIP_TRY(hipMalloc(&tmp, (size_t)n * ld * 8));
-        hipLaunchKernelGGL(k_i32_to_f64, dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, ctx->d_i32, n, ld, tmp);
+        if (ctx->elem == TSPGPU_ELEM_I32)
+            hipLaunchKernelGGL((k_to_f64<int>), dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, (const int *)ctx->d_mat, n, ld, tmp);
+        else
+            hipLaunchKernelGGL((k_to_f64<u16>), dim3((ld + 255) / 256, n), dim3(256), 0, ctx->stream, (const u16 *)ctx->d_mat, n, ld, tmp);
         src = tmp;
     }
     hipError_t e = hipMemcpy2DAsync(host_out, (size_t)n * 8, src, (size_t)ld * 8, (size_t)n * 8, n, hipMemcpyDeviceToHost, ctx->stream);
