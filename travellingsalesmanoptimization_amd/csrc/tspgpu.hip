@@ -102,6 +102,31 @@ __device__ __forceinline__ double vget(const v2f64 &v, int i) { return v[i]; }
 __device__ __forceinline__ int vget(const v4i32 &v, int i) { return v[i]; }
 __device__ __forceinline__ int vget(const v8u16 &v, int i) { return (int)v[i]; }
 
+// V consecutive elements starting at p (16-byte vector loads; the arrays carry slack behind
+// the last tour so that a read up to V-1 elements past n stays inside the allocation)
+template <int V, typename E>
+__device__ __forceinline__ void load_run(const E *p, E (&out)[V])
+{
+    constexpr int PER = 16 / (int)sizeof(E);
+    typedef E vec_t __attribute__((ext_vector_type(PER)));
+    static_assert(V % PER == 0 || V < PER, "run must be whole vectors");
+    if constexpr (V >= PER) {
+#pragma unroll
+        for (int k = 0; k < V / PER; k++) {
+            vec_t x;
+            __builtin_memcpy(&x, p + k * PER, sizeof x);
+#pragma unroll
+            for (int e = 0; e < PER; e++) out[k * PER + e] = x[e];
+        }
+    } else {
+        typedef E half_t __attribute__((ext_vector_type(V)));
+        half_t x;
+        __builtin_memcpy(&x, p, sizeof x);
+#pragma unroll
+        for (int e = 0; e < V; e++) out[e] = x[e];
+    }
+}
+
 __device__ __forceinline__ bool key_better(double d1, u64 k1, double d2, u64 k2)
 {
     return d1 < d2 || (d1 == d2 && k1 < k2);
@@ -217,6 +242,10 @@ __global__ void __launch_bounds__(256) k_to_f64(const TS *__restrict__ m, int n,
 //   dpos[p]  cost of the tour edge between array positions p and p+1 (cyclic),
 //            in the tour's current direction
 //   dir      +1: succ(ord[p]) = ord[p+1];  -1: succ(ord[p]) = ord[p-1]
+//   succ[b], dnb[b]  node-indexed view for the sweeps: successor of b and c[b][succ b],
+//            rebuilt by k_apply after each move so that every sweep workgroup reads them
+//            with coalesced loads (deriving them per workgroup from pos/ord/dpos costs n
+//            random reads per workgroup: measured 3-7 us per sweep)
 //
 // A 2-opt move flips one of the two arcs the removed edges cut the cycle into.
 // ref_reverse_path flips the arc succ_a .. b; flipping the OTHER arc and
@@ -226,8 +255,8 @@ __global__ void __launch_bounds__(256) k_to_f64(const TS *__restrict__ m, int n,
 // edges {a,b}, {succ_a,succ_b} are new: two matrix reads per move.
 // ---------------------------------------------------------------------------
 struct Tours {
-    int *ord, *pos, *succ;   // [cap][n]; succ is filled on export only
-    double *dpos;            // [cap][n] 8-byte slots; int32 mode uses the first 4n bytes of each
+    int *ord, *pos, *succ;   // [cap][n]
+    double *dpos, *dnb;      // [cap][n] 8-byte slots; integer modes use the first 4n bytes of each
     double *cost, *last_delta; // [cap]
     int *dir, *done, *nsweeps, *cap_sweeps, *status; // [cap]
     Partial *partial;        // [cap][MAX_WGS_PER_TOUR]
@@ -244,6 +273,11 @@ template <typename T>
 __device__ __forceinline__ T *dpos_of(const Tours &S, int t, int n)
 {
     return reinterpret_cast<T *>(S.dpos + (size_t)t * n);
+}
+template <typename T>
+__device__ __forceinline__ T *dnb_of(const Tours &S, int t, int n)
+{
+    return reinterpret_cast<T *>(S.dnb + (size_t)t * n);
 }
 
 __device__ __forceinline__ int wrap(int p, int n) { return p < 0 ? p + n : (p >= n ? p - n : p); }
@@ -264,17 +298,22 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     const int *ord = S.ord + (size_t)t * n;
     int *pos = S.pos + (size_t)t * n;
     AT *dp = dpos_of<AT>(S, t, n);
+    AT *dnb = dnb_of<AT>(S, t, n);
+    int *succ = S.succ + (size_t)t * n;
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
         const int node = ord[p];
         const int s = ord[p + 1 == n ? 0 : p + 1];
+        const AT w = (AT)mat[(size_t)node * ld + s];
         pos[node] = p;
-        dp[p] = (AT)mat[(size_t)node * ld + s];
+        dp[p] = w;
+        succ[node] = s;
+        dnb[node] = w;
     }
     __syncthreads();
     double total = 0;
     if constexpr (std::is_same<AT, int>::value) {
         long long part = 0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) part += dp[i];
+        for (int i = threadIdx.x; i < n; i += blockDim.x) part += dnb[i];
         for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
         long long *acc = reinterpret_cast<long long *>(chunk);
         if ((threadIdx.x & 63) == 0) acc[threadIdx.x >> 6] = part;
@@ -287,7 +326,7 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     } else {
         for (int base = 0; base < n; base += 1024) {
             const int m = min(1024, n - base);
-            for (int i = threadIdx.x; i < m; i += blockDim.x) chunk[i] = dp[pos[base + i]]; // c[i][succ i]
+            for (int i = threadIdx.x; i < m; i += blockDim.x) chunk[i] = dnb[base + i]; // c[i][succ i]
             __syncthreads();
             if (threadIdx.x == 0)
                 for (int i = 0; i < m; i++) total += chunk[i];
@@ -435,9 +474,9 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)ld * sizeof(T));
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
-    const int *pos = A.S.pos + (size_t)t * n;
     typedef typename Elem<T>::acc AT;
-    const AT *dp = dpos_of<AT>(A.S, t, n);
+    const int *succ = A.S.succ + (size_t)t * n;
+    const AT *dnb = dnb_of<AT>(A.S, t, n);
     const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
@@ -462,21 +501,20 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
         if constexpr (TABU) {
             if (is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure)) continue;
         }
-        const AT d_a = dp[p];
+        const AT d_a = dnb[a];
         const T *rowA = mat + (size_t)a * ld;
         const int kmax = A.symmetric ? n / 2 : n - 1 - a;
         for (int k = 1 + tid; k <= kmax; k += BT) {
             int b = a + k;
             if (b >= n) b -= n;
-            const int q = pos[b];
-            const int sb = ord[wrap(q + dir, n)];
+            const int sb = succ[b];
             if (b == sa || sb == a) continue;          // refinment.c:55
             if (!pair_owned(a, b, n, A.symmetric)) continue;
             if constexpr (TABU) {
                 if (is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure)) continue;
             }
             const AT made = (AT)rowA[b] + (AT)rowS[sb];              // c[a][b] + c[sa][sb]
-            const AT kept = d_a + dp[dir > 0 ? q : wrap(q - 1, n)];  // c[a][sa] + c[b][sb]
+            const AT kept = d_a + dnb[b];                            // c[a][sa] + c[b][sb]
             consider<AT>(made - kept, a, b, best_d, best_key);
         }
     }
@@ -551,14 +589,28 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     const T BIG = Elem<T>::big();
     int sboff[NCH][V];
     T dnv[NCH][V];
-    int q[NCH][V];
+    {
+        const int *succ = A.S.succ + (size_t)t * n;
+        const T *dnb = dnb_of<T>(A.S, t, n);
 #pragma unroll
-    for (int c = 0; c < NCH; c++)
+        for (int c = 0; c < NCH; c++) {
+            const int b0 = min((c * BT + tid) * V, ld - V);
+            int sv[V];
+            T dv[V];
+            load_run<V>(succ + b0, sv);
+            load_run<V>(dnb + b0, dv);
 #pragma unroll
-        for (int v = 0; v < V; v++) {
-            const int b = (c * BT + tid) * V + v;
-            q[c][v] = b < n ? pos[b] : 0;
+            for (int v = 0; v < V; v++) {
+                const int b = (c * BT + tid) * V + v;
+                const int sb = b < n ? sv[v] : 0;
+                bool sk = b >= n;
+                if constexpr (TABU)
+                    if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
+                sboff[c][v] = sb * (int)sizeof(T);
+                dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+            }
         }
+    }
     __syncthreads(); // nodes[] visible
     STAMP(1);
 
@@ -581,19 +633,6 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     // row r travels through register set r % D
 #pragma unroll
     for (int r = 0; r < D; r++) issue(R[r], r);
-#pragma unroll
-    for (int c = 0; c < NCH; c++)
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-            const int b = (c * BT + tid) * V + v;
-            const int sb = ord[wrap(q[c][v] + dir, n)];
-            T dn = dp[dir > 0 ? q[c][v] : wrap(q[c][v] - 1, n)];
-            bool sk = b >= n;
-            if constexpr (TABU)
-                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-            sboff[c][v] = sb * (int)sizeof(T);
-            dnv[c][v] = sk ? -BIG : dn;   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
-        }
     // prep(s): make the landed row of a_s ready to be the "row a" buffer of step s.  The
     // three pairs the reference skips (refinment.c:55: b == a, b == succ a, succ b == a,
     // i.e. b in {a_s, a_s+1, a_s-1}) are removed by poisoning their c[a][b] cells, after
@@ -761,20 +800,48 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
 
+    unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
+#define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
+    STAMP(0);
     const int p0 = blockIdx.x * A.P;
     const int cnt = min(A.P, n - p0);
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
     for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
 
-    int q[NCH][V];
+    // per-thread state of the owned b's: coalesced loads of the node-indexed view.  Issued
+    // BEFORE the matrix rows: vector loads return in order, so anything younger than the rows
+    // would only become usable after the last row has arrived.
+    const int *succ = A.S.succ + (size_t)t * n;
+    const AT *dnb = dnb_of<AT>(A.S, t, n);
+    const AT BIG = Elem<T>::big();
+    int sboff[NCH][V], jb[NCH][V];
+    AT dnv[NCH][V];
 #pragma unroll
-    for (int c = 0; c < NCH; c++)
+    for (int c = 0; c < NCH; c++) {
+        const int b0 = min((c * BT + tid) * V, ld - V);   // lanes past the row: masked below
+        int qv[V], sv[V];
+        AT dv[V];
+        load_run<V>(pos + b0, qv);
+        load_run<V>(succ + b0, sv);
+        load_run<V>(dnb + b0, dv);
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int b = (c * BT + tid) * V + v;
-            q[c][v] = b < n ? pos[b] : 0;
+            const int qb = qv[v], sb = b < n ? sv[v] : 0;
+            bool sk = b >= n;
+            if constexpr (TABU)
+                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
+            sboff[c][v] = sb * (int)sizeof(T);
+            dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+            // step index whose node a_j is b (run positions p0 .. p0+cnt, walked along dir), else far away
+            int j = dir > 0 ? qb - p0 : p0 + cnt - qb;
+            if (j < -1) j += n;              // the run may wrap past position n-1 / below 0
+            if (j > n - 2) j -= n;
+            jb[c][v] = ((b < n && j >= -1 && j <= cnt) ? j : 1 << 20) - 1;   // invalid steps: jb .. jb+2
         }
+    }
     __syncthreads(); // nodes[] visible
+    STAMP(1);
 
     // every row of the run in flight at once
     VT R[PMAX + 1][NCH];
@@ -787,52 +854,25 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
         }
     }
 
-    // per-thread state of the owned b's (loads that depend on pos[b], issued behind the rows)
-    const AT BIG = Elem<T>::big();
-    int sboff[NCH][V], jb[NCH][V];
-    AT dnv[NCH][V];
-#pragma unroll
-    for (int c = 0; c < NCH; c++)
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-            const int b = (c * BT + tid) * V + v;
-            const int sb = ord[wrap(q[c][v] + dir, n)];
-            const AT dn = dp[dir > 0 ? q[c][v] : wrap(q[c][v] - 1, n)];
-            bool sk = b >= n;
-            if constexpr (TABU)
-                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-            sboff[c][v] = sb * (int)sizeof(T);
-            dnv[c][v] = sk ? -BIG : dn;      // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
-            // step index whose node a_j is b (run positions p0 .. p0+cnt, walked along dir), else far away
-            int j = dir > 0 ? q[c][v] - p0 : p0 + cnt - q[c][v];
-            if (j < -1) j += n;              // the run may wrap past position n-1 / below 0
-            if (j > n - 2) j -= n;
-            jb[c][v] = (b < n && j >= -1 && j <= cnt) ? j : 1 << 20;
-        }
-
-#pragma unroll
-    for (int r = 0; r <= PMAX; r++) {
-        if (r <= cnt && A.ablate != 2) {
-            VT *dst = reinterpret_cast<VT *>(rows + (size_t)r * ld);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[r][c];
-        }
-    }
-    __syncthreads(); // the only barrier in front of the step loop
-
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
+    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
+    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
+    constexpr bool PACKED = std::is_same<AT, int>::value;
+    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
     AT best_d = TABU ? Elem<T>::lim() : (AT)0;
     int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
     bool have = false;
 
-    for (int s = 0; s < cnt; s++) {
+    auto step = [&](int s) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
         const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
         const T *bA = rows + (size_t)s * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
+        if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         bool live = A.ablate != 1;
         if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
-        if (!live) continue;
+        if (!live) return;
         const AT d_a = (AT)bA[sa];            // c[a][succ a]
         // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
         const int lo = a + 1 == n ? 0 : a + 1;
@@ -851,38 +891,103 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
             AT g[V];
 #pragma unroll
             for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
+            if constexpr (PACKED) {
+                // groups of 4 independent keys + a min tree each: short dependency chains, and the
+                // only serial dependency on best_k is one compare per chunk
+                auto keys = [&](auto check_tag) __attribute__((always_inline)) {
+                    constexpr bool CHECK = decltype(check_tag)::value;
+                    constexpr int GR = V < 4 ? V : 4;
+                    long long acc = 0x7fffffffffffffffll;
 #pragma unroll
-            for (int v = 0; v < V; v++) {
-                const int b = b0 + v;
-                AT delta;
-                if constexpr (std::is_same<AT, int>::value) delta = (AT)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
-                else { const AT made = (AT)vget(xa, v) + g[v]; const AT kept = d_a + dnv[c][v]; delta = made - kept; } // refinment.c:58-60
-                bool ok = (unsigned)(s - jb[c][v] + 1) > 2u;   // not b in {pred a, a, succ a}
-                if (!inside) {
-                    int tt = b - lo;
-                    tt += (tt >> 31) & n;
-                    ok &= (unsigned)tt < (unsigned)len;
-                }
-                const bool lt = ok & (delta < best_d);
-                bool eq = ok & (delta == best_d);
-                if constexpr (!TABU) eq &= delta < (AT)0;
-                if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
-                    if (eq) {
-                        const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
-                        const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
-                                                       : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
-                        if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                    for (int v0 = 0; v0 < V; v0 += GR) {
+                        long long key[GR];
+#pragma unroll
+                        for (int u = 0; u < GR; u++) {
+                            const int v = v0 + u;
+                            const int b = b0 + v;
+                            bool ok = (unsigned)(s - jb[c][v]) > 2u;   // not b in {pred a, a, succ a}
+                            if constexpr (CHECK) {
+                                int tt = b - lo;
+                                tt += (tt >> 31) & n;
+                                ok &= (unsigned)tt < (unsigned)len;
+                            }
+                            int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
+                            delta = ok ? delta : BIG;
+                            const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                            key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
+                        }
+#pragma unroll
+                        for (int w = GR / 2; w >= 1; w /= 2)
+#pragma unroll
+                            for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
+                        acc = key[0] < acc ? key[0] : acc;
                     }
+                    best_k = acc < best_k ? acc : best_k;
+                };
+                if (inside) keys(std::false_type{}); else keys(std::true_type{});
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    const int b = b0 + v;
+                    bool ok = (unsigned)(s - jb[c][v]) > 2u;       // not b in {pred a, a, succ a}
+                    if (!inside) {
+                        int tt = b - lo;
+                        tt += (tt >> 31) & n;
+                        ok &= (unsigned)tt < (unsigned)len;
+                    }
+                    const AT made = (AT)vget(xa, v) + g[v];
+                    const AT kept = d_a + dnv[c][v];
+                    const AT delta = made - kept;               // refinment.c:58-60
+                    const bool lt = ok & (delta < best_d);
+                    bool eq = ok & (delta == best_d);
+                    if constexpr (!TABU) eq &= delta < (AT)0;
+                    if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                        if (eq) {
+                            const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                            const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                           : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                            if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                        }
+                    }
+                    best_d = lt ? delta : best_d;
+                    best_a = lt ? a : best_a;
+                    best_b = lt ? b : best_b;
+                    have = have | lt;
                 }
-                best_d = lt ? delta : best_d;
-                best_a = lt ? a : best_a;
-                best_b = lt ? b : best_b;
-                have = have | lt;
             }
+        }
+    };
+
+    // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
+    // are in LDS runs while the later rows are still in flight (3 barriers in all for P = 8).
+    constexpr int RPC = 3;
+    {
+        int s = 0;
+#pragma unroll
+        for (int r0 = 0; r0 <= PMAX; r0 += RPC) {
+#pragma unroll
+            for (int r = r0; r < r0 + RPC && r <= PMAX; r++) {
+                if (r <= cnt && A.ablate != 2) {
+                    VT *dst = reinterpret_cast<VT *>(rows + (size_t)r * ld);
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[r][c];
+                }
+            }
+            __syncthreads();
+            if (r0 == 0) STAMP(2);
+            const int s_end = min(cnt, r0 + RPC - 1);   // steps s with row s+1 <= r0+RPC-1
+            for (; s < s_end; s++) step(s);
         }
     }
 
+    STAMP(3);
     // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
+    if constexpr (PACKED) {
+        best_d = (AT)(int)(best_k >> 32);
+        best_a = (int)(((unsigned)best_k) >> 16);
+        best_b = (int)(((unsigned)best_k) & 0xffffu);
+        have = TABU ? best_d < BIG / 2 : best_d < 0;
+    }
     double d = (double)best_d;
     u64 key;
     if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
@@ -892,6 +997,8 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
         Partial o; o.d = d; o.key = key;
         A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
     }
+    STAMP(4);
+#undef STAMP
 }
 
 // ---------------------------------------------------------------------------
@@ -985,6 +1092,17 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
             }
         }
         if (other) { ndir = -dir; if (tid == 0) A.S.dir[t] = ndir; }
+        // node-indexed view for the next sweep (all n nodes: branch-free, n/BT per thread)
+        __syncthreads();
+        {
+            int *succ = A.S.succ + (size_t)t * n;
+            AT *dnb = dnb_of<AT>(A.S, t, n);
+            for (int v = tid; v < n; v += BT) {
+                const int qv = pos[v];
+                succ[v] = ord[wrap(qv + ndir, n)];
+                dnb[v] = dp[ndir > 0 ? qv : wrap(qv - 1, n)];
+            }
+        }
     }
     if constexpr (TABU) {
         TabuState *ts = A.tabu;
@@ -993,8 +1111,10 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
         if (move) cost_now += d;
         const bool improved = ts->resident && cost_now < ts->best_cost;
         __syncthreads(); // ord[]/dir final; all threads have read ts->iter / best_cost
-        if (improved && A.best_succ)
-            for (int p = tid; p < n; p += BT) A.best_succ[ord[p]] = ord[wrap(p + ndir, n)];
+        if (improved && A.best_succ) {
+            const int *succ = A.S.succ + (size_t)t * n;
+            for (int v = tid; v < n; v += BT) A.best_succ[v] = succ[v];
+        }
         if (tid == 0) {
             if (move) {
                 A.S.cost[t] = cost_now;
@@ -1032,6 +1152,8 @@ __global__ void k_copy_tour(Tours S, int n, int dst, int src)
         S.ord[(size_t)dst * n + i] = S.ord[(size_t)src * n + i];
         S.pos[(size_t)dst * n + i] = S.pos[(size_t)src * n + i];
         S.dpos[(size_t)dst * n + i] = S.dpos[(size_t)src * n + i];
+        S.succ[(size_t)dst * n + i] = S.succ[(size_t)src * n + i];
+        S.dnb[(size_t)dst * n + i] = S.dnb[(size_t)src * n + i];
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         S.cost[dst] = S.cost[src]; S.last_delta[dst] = S.last_delta[src];
@@ -1131,7 +1253,7 @@ static void free_matrix(tspgpu_ctx *ctx)
 static void free_tours(tspgpu_ctx *ctx)
 {
     Tours &S = ctx->S;
-    void *ptrs[] = {S.ord, S.pos, S.succ, S.dpos, S.cost, S.last_delta, S.dir, S.done, S.nsweeps, S.cap_sweeps, S.status,
+    void *ptrs[] = {S.ord, S.pos, S.succ, S.dpos, S.dnb, S.cost, S.last_delta, S.dir, S.done, S.nsweeps, S.cap_sweeps, S.status,
                     S.partial, ctx->d_starts, ctx->d_caps, ctx->d_tabu_list, ctx->d_best_succ, ctx->d_tabu};
     for (void *p : ptrs) if (p) hipFree(p);
     if (ctx->h_status) hipHostFree(ctx->h_status);
@@ -1153,10 +1275,15 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
     }
     const size_t T = (size_t)want, N = (size_t)n;
     Tours &S = ctx->S;
-    HIP_TRY(hipMalloc(&S.ord, T * N * 4));
-    HIP_TRY(hipMalloc(&S.pos, T * N * 4));
-    HIP_TRY(hipMalloc(&S.succ, T * N * 4));
-    HIP_TRY(hipMalloc(&S.dpos, T * N * 8));
+    const size_t slack = 64; // vector reads of the last tour's tail (load_run)
+    HIP_TRY(hipMalloc(&S.ord, (T * N + slack) * 4));
+    HIP_TRY(hipMalloc(&S.pos, (T * N + slack) * 4));
+    HIP_TRY(hipMalloc(&S.succ, (T * N + slack) * 4));
+    HIP_TRY(hipMalloc(&S.dpos, (T * N + slack) * 8));
+    HIP_TRY(hipMalloc(&S.dnb, (T * N + slack) * 8));
+    HIP_TRY(hipMemsetAsync(S.pos, 0, (T * N + slack) * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.succ, 0, (T * N + slack) * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.dnb, 0, (T * N + slack) * 8, ctx->stream));
     HIP_TRY(hipMalloc(&S.dir, T * 4));
     HIP_TRY(hipMalloc(&S.cost, T * 8));
     HIP_TRY(hipMalloc(&S.last_delta, T * 8));
@@ -1522,11 +1649,7 @@ static int load_path(tspgpu_ctx *ctx, int slot, const int *path, int cap)
 static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
 {
     const int n = ctx->n;
-    if (path) {
-        hipLaunchKernelGGL(k_export_succ, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, ctx->S, n, slot);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(path, ctx->S.succ + (size_t)slot * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
-    }
+    if (path) HIP_TRY(hipMemcpyAsync(path, ctx->S.succ + (size_t)slot * n, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (cost) HIP_TRY(hipMemcpyAsync(cost, ctx->S.cost + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
     if (last_delta) HIP_TRY(hipMemcpyAsync(last_delta, ctx->S.last_delta + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
