@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cpu-sweeps", type=int, default=150, help="bounded CPU baseline sample (0 = skip)")
+    ap.add_argument("--batch-starts", type=int, default=64, help="starts of the batched multi-start leg (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
     args = ap.parse_args()
 
@@ -239,6 +240,20 @@ def main():
                  "traffic": load_traffic(f"n{n}_{oelem}")}
         e2.close()
 
+    # ---- batched multi-start on the same instance (h_greedy_2opt's loop, 64 starts in flight):
+    # the throughput-bound regime, next to the latency-bound single search above
+    batch = None
+    if rank == 0 and world == 1 and args.batch_starts > 0:
+        starts = np.arange(args.batch_starts, dtype=np.int32)
+        eng.multistart_nn_2opt(starts[:4])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = eng.multistart_nn_2opt(starts)
+        dtb = time.perf_counter() - t1
+        batch = {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
+                 "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"],
+                 "includes": "NN construction + 2-opt of every start, host arrays in/out"}
+
     if rank == 0:
         info = eng.info()
         out = {
@@ -262,7 +277,7 @@ def main():
             "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
             "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost,
             "matrix_build_ms": build_ms, "nn_tour_ms": nn_ms,
-            "roofline": roof, "cpu_baseline": base, "other_matrix_storage": other,
+            "roofline": roof, "cpu_baseline": base, "other_matrix_storage": other, "multistart_batch": batch,
         }
         if base:
             out["gpu_over_cpu"] = out["value"] / base["value"]

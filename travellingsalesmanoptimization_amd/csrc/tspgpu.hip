@@ -1389,7 +1389,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     const size_t slack = 1024; // nodes[] + reduction scratch
 
     int BT = ctx->opt_block;
-    if (BT <= 0) BT = std::min(1024, std::max(64, pow2_ceil(nvec)));
+    if (BT <= 0) BT = std::min(1024, std::max(64, (nvec + 63) & ~63)); // one 16-byte vector per thread, whole waves
     BT = std::min(1024, std::max(64, (BT + 63) & ~63));
 
     int kernel = ctx->opt_kernel;
@@ -1416,7 +1416,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     if (ctx->elem == TSPGPU_ELEM_U16 && kernel == 2) return fail(ctx, E_INVALID, "the pipelined sweep has no uint16 variant");
     // resident sweep: all P+1 (<= 9) rows of a run in LDS at once.  One chunk per thread for
     // uint16 (two would spill), at most two otherwise.
-    const int res_bt = std::min(1024, std::max(64, pow2_ceil(nvec)));
+    const int res_bt = std::min(1024, std::max(64, (nvec + 63) & ~63));
     const int res_nch = (nvec + res_bt - 1) / res_bt;
     auto res_P = [&]() { // rows that fit: prefer two workgroups per CU when that still gives P = 8
         const size_t extra = slack + 64;
