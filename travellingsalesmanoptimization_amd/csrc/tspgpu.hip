@@ -1067,37 +1067,71 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
         const int x2 = ord[wrap(lo + M - 1, n)], x3 = ord[wrap(lo + M, n)];
         sa = ord[wrap(i + dir, n)];
         sb = ord[wrap(j + dir, n)];
-        // cells: swap k <-> M-1-k ; inner edges (M-1 of them): swap k <-> M-2-k
-        __syncthreads(); // everybody has read pos/ord before they change
-        for (int k = tid; k < M / 2; k += BT) {
-            const int pk = wrap(lo + k, n), qk = wrap(lo + M - 1 - k, n);
-            const int u = ord[pk], v = ord[qk];
-            ord[pk] = v; ord[qk] = u;
-            pos[v] = pk; pos[u] = qk;
-        }
+        int *succ = A.S.succ + (size_t)t * n;
+        AT *dnb = dnb_of<AT>(A.S, t, n);
+        if (other) ndir = -dir;
         if (A.symmetric) {
+            // Node-indexed view, from the OLD arrays only (one independent round of loads): the
+            // nodes of the reference's arc succ_a .. b now point at their old predecessors, over
+            // the same edges (symmetric costs); succ_a and a get the two new edges below.
+            // (four elements per thread per round: all loads first, then the stores -- the
+            // stores go through pointers the compiler cannot prove distinct from the loads)
+            for (int k0 = 2 + tid; k0 <= L; k0 += 4 * BT) {
+                int vv[4], pr[4];
+                AT ww[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int k = min(k0 + u * BT, L);
+                    const int p = wrap(i + dir * k, n), pp = wrap(i + dir * (k - 1), n);
+                    vv[u] = ord[p];
+                    pr[u] = ord[pp];
+                    ww[u] = dp[dir > 0 ? pp : p];   // edge between array cells pp and p
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {       // (a clamped duplicate rewrites the same values)
+                    succ[vv[u]] = pr[u];
+                    dnb[vv[u]] = ww[u];
+                }
+            }
+            // the two new edges {a,b} and {succ a, succ b}: they are also the arc's boundary cells
+            const AT wA = (AT)mat[(size_t)x0 * ld + x2], wB = (AT)mat[(size_t)x1 * ld + x3];
+            const bool a_in_A = x0 == a || x2 == a;
+            __syncthreads(); // every read of the old ord/dpos is complete
+            // cells: swap k <-> M-1-k ; inner edges (M-1 of them): swap k <-> M-2-k
+            for (int k = tid; k < M / 2; k += BT) {
+                const int pk = wrap(lo + k, n), qk = wrap(lo + M - 1 - k, n);
+                const int u = ord[pk], v = ord[qk];
+                ord[pk] = v; ord[qk] = u;
+                pos[v] = pk; pos[u] = qk;
+            }
             for (int k = tid; k < (M - 1) / 2; k += BT) {
                 const int pe = wrap(lo + k, n), qe = wrap(lo + M - 2 - k, n);
                 const AT eu = dp[pe], ev = dp[qe];
                 dp[pe] = ev; dp[qe] = eu;
             }
-            if (tid == 0) dp[wrap(lo - 1, n)] = (AT)mat[(size_t)x0 * ld + x2];
-            if (tid == 64 % BT) dp[wrap(lo + M - 1, n)] = (AT)mat[(size_t)x1 * ld + x3];
+            if (tid == 0) {
+                dp[wrap(lo - 1, n)] = wA;
+                dp[wrap(lo + M - 1, n)] = wB;
+                succ[a] = b;   dnb[a] = a_in_A ? wA : wB;
+                succ[sa] = sb; dnb[sa] = a_in_A ? wB : wA;
+                if (other) A.S.dir[t] = ndir;
+            }
         } else {
+            __syncthreads(); // everybody has read pos/ord before they change
+            for (int k = tid; k < M / 2; k += BT) {
+                const int pk = wrap(lo + k, n), qk = wrap(lo + M - 1 - k, n);
+                const int u = ord[pk], v = ord[qk];
+                ord[pk] = v; ord[qk] = u;
+                pos[v] = pk; pos[u] = qk;
+            }
             __syncthreads(); // cells final; re-read the costs of edges lo-1 .. lo+M-1 in tour direction
             for (int k = tid; k <= M; k += BT) {
                 const int pe = wrap(lo - 1 + k, n);
                 const int un = ord[pe], vn = ord[wrap(pe + 1, n)];
                 dp[pe] = (AT)(dir > 0 ? mat[(size_t)un * ld + vn] : mat[(size_t)vn * ld + un]);
             }
-        }
-        if (other) { ndir = -dir; if (tid == 0) A.S.dir[t] = ndir; }
-        // node-indexed view for the next sweep (all n nodes: branch-free, n/BT per thread)
-        __syncthreads();
-        {
-            int *succ = A.S.succ + (size_t)t * n;
-            AT *dnb = dnb_of<AT>(A.S, t, n);
-            for (int v = tid; v < n; v += BT) {
+            __syncthreads();
+            for (int v = tid; v < n; v += BT) {   // direction-bound costs: rebuild the whole view
                 const int qv = pos[v];
                 succ[v] = ord[wrap(qv + ndir, n)];
                 dnb[v] = dp[ndir > 0 ? qv : wrap(qv - 1, n)];
