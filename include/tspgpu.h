@@ -46,7 +46,7 @@ enum { TSPGPU_ELEM_AUTO = 0, TSPGPU_ELEM_F64 = 1, TSPGPU_ELEM_I32 = 2, TSPGPU_EL
 /* tunables (tspgpu_set_option) */
 enum {
     TSPGPU_OPT_ELEM = 1,        /* TSPGPU_ELEM_*; takes effect at the next build/set_costs */
-    TSPGPU_OPT_KERNEL = 2,      /* 0 auto, 1 "simple", 2 "pipelined", 3 "resident" sweep kernel */
+    TSPGPU_OPT_KERNEL = 2,      /* 0 auto, 1 "simple", 2 "pipelined", 3 "resident" sweep kernel (info reports 4 = matrix-free) */
     TSPGPU_OPT_BATCH = 3,       /* sweeps enqueued between host polls (default 32) */
     TSPGPU_OPT_WGS_PER_TOUR = 4,/* workgroups per tour in the sweep (0 = auto) */
     TSPGPU_OPT_HISTORY = 5,     /* record (a,b,delta) of the first N sweeps of slot 0 */
@@ -54,7 +54,9 @@ enum {
     TSPGPU_OPT_TIMING = 7,      /* 1 = bracket every sweep kernel with HIP events */
     TSPGPU_OPT_BLOCK = 8,       /* threads per sweep workgroup (0 = auto) */
     TSPGPU_OPT_MAX_TOURS = 9,   /* tours kept in flight by the multi-start driver */
-    TSPGPU_OPT_DEPTH = 10       /* matrix rows in flight per workgroup in the pipelined sweep (0 = auto) */
+    TSPGPU_OPT_DEPTH = 10,      /* matrix rows in flight per workgroup in the pipelined sweep (0 = auto) */
+    TSPGPU_OPT_MATRIX_FREE = 11 /* 0 auto (matrix-free when a matrix row cannot sit in LDS), 1 always, 2 never;
+                                   takes effect at the next tspgpu_build_costs */
 };
 
 int  tspgpu_device_count(void);
@@ -64,7 +66,8 @@ const char *tspgpu_last_error(const tspgpu_ctx *ctx);
 int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
 /* info: 0 n, 1 row stride, 2 element kind in use, 3 sweep kernel in use,
  * 4 workgroups per tour, 5 LDS bytes per workgroup, 6 threads per workgroup,
- * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup */
+ * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup,
+ * 10 matrix-free mode in use */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

@@ -355,6 +355,77 @@ int orc_vns(const double *c, int n, int *succ, double *cost, int k,
     return 0;
 }
 
+/* ------------------------------------------------ matrix-free variants --- */
+/* Same algorithms with every c[i][j] recomputed from the coordinates (edge_weight above):
+ * for instances whose n x n matrix does not fit (pla85900: 59 GB of doubles).  Results are
+ * identical to the matrix versions by construction; tests check that on small instances. */
+
+int orc_nn_tour_xy(const double *xy, int n, int kind, int start, int *succ, double *cost)
+{
+    if (start < 0 || start >= n) return 14;
+    unsigned char *seen = (unsigned char *)calloc((size_t)n, 1);
+    int cur = start;
+    double total = 0;
+    seen[cur] = 1;
+    for (;;) {
+        int arg = -1;
+        double lo = DBL_MAX;
+        const double cx = xy[2 * cur], cy = xy[2 * cur + 1];
+        for (int i = 0; i < n; i++) {
+            if (i == cur || seen[i]) continue;
+            double w = edge_weight(cx, cy, xy[2 * i], xy[2 * i + 1], kind);
+            if (w < lo) { lo = w; arg = i; }
+        }
+        if (arg < 0) { succ[cur] = start; break; }
+        succ[cur] = arg;
+        seen[arg] = 1;
+        total += lo;
+        cur = arg;
+    }
+    total += edge_weight(xy[2 * cur], xy[2 * cur + 1], xy[2 * start], xy[2 * start + 1], kind);
+    *cost = total;
+    free(seen);
+    return 0;
+}
+
+double orc_tour_cost_xy(const double *xy, int n, int kind, const int *succ)
+{
+    double s = 0;
+    for (int i = 0; i < n; i++) s += edge_weight(xy[2 * i], xy[2 * i + 1], xy[2 * succ[i]], xy[2 * succ[i] + 1], kind);
+    return s;
+}
+
+double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double *cost, int *move_ab)
+{
+    double best = 0;
+    int ba = -1, bb = -1;
+    double *dn = (double *)malloc(sizeof(double) * (size_t)n);   /* c[b][succ b] */
+    for (int b = 0; b < n; b++) dn[b] = edge_weight(xy[2 * b], xy[2 * b + 1], xy[2 * succ[b]], xy[2 * succ[b] + 1], kind);
+    for (int a = 0; a < n - 1; a++) {
+        const int sa = succ[a];
+        const double ax = xy[2 * a], ay = xy[2 * a + 1], sx = xy[2 * sa], sy = xy[2 * sa + 1];
+        for (int b = a + 1; b < n; b++) {
+            const int sb = succ[b];
+            if (sa == sb || a == sb || b == sa) continue;
+            double kept = dn[a] + dn[b];
+            double made = edge_weight(ax, ay, xy[2 * b], xy[2 * b + 1], kind) +
+                          edge_weight(sx, sy, xy[2 * sb], xy[2 * sb + 1], kind);
+            double d = made - kept;
+            if (d < best) { best = d; ba = a; bb = b; }
+        }
+    }
+    free(dn);
+    if (move_ab) { move_ab[0] = ba; move_ab[1] = bb; }
+    if (best < ORC_EPS) {
+        int *prev = (int *)malloc(sizeof(int) * (size_t)n);
+        fill_prev(succ, n, prev);
+        orc_reverse_path(ba, succ[ba], bb, succ[bb], prev, succ, n);
+        *cost += best;
+        free(prev);
+    }
+    return best;
+}
+
 /* ---------------------------------------------------------- validation --- */
 
 int orc_valid_tour(const int *succ, int n)

@@ -90,6 +90,11 @@ int orc_vns_kick(int n, int *succ);
 int orc_vns(const double *c, int n, int *succ, double *cost, int k,
             int *best_succ, double *best_cost);
 
+/* matrix-free variants (weights recomputed from coordinates; same results) */
+int orc_nn_tour_xy(const double *xy, int n, int kind, int start, int *succ, double *cost);
+double orc_tour_cost_xy(const double *xy, int n, int kind, const int *succ);
+double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double *cost, int *move_ab);
+
 /* src/tsp.c:642-667 + :687-728  tsp_validate_solution / tsp_is_tour. */
 int orc_valid_tour(const int *succ, int n);
 

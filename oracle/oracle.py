@@ -56,6 +56,11 @@ def lib():
         L.orc_vns_kick.argtypes = [C.c_int, _ip]
         L.orc_vns.argtypes = [_dp, C.c_int, _ip, C.POINTER(C.c_double), C.c_int, _ip,
                               C.POINTER(C.c_double)]
+        L.orc_nn_tour_xy.argtypes = [_dp, C.c_int, C.c_int, C.c_int, _ip, C.POINTER(C.c_double)]
+        L.orc_tour_cost_xy.argtypes = [_dp, C.c_int, C.c_int, _ip]
+        L.orc_tour_cost_xy.restype = C.c_double
+        L.orc_two_opt_once_xy.argtypes = [_dp, C.c_int, C.c_int, _ip, C.POINTER(C.c_double), _ip]
+        L.orc_two_opt_once_xy.restype = C.c_double
         L.orc_valid_tour.argtypes = [_ip, C.c_int]
         L.orc_fnv1a.argtypes = [_ip, C.c_int]
         L.orc_fnv1a.restype = C.c_uint64
@@ -181,6 +186,31 @@ def vns(c, succ, cost, k):
     best = np.empty(n, dtype=np.int32)
     lib().orc_vns(c.reshape(-1), n, succ, C.byref(cc), k, best, C.byref(bc))
     return best, bc.value
+
+
+def nn_tour_xy(xy, kind, start):
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    n = len(xy) // 2
+    succ = np.empty(n, dtype=np.int32)
+    cost = C.c_double()
+    rc = lib().orc_nn_tour_xy(xy, n, kind, start, succ, C.byref(cost))
+    if rc:
+        raise ValueError(f"orc_nn_tour_xy -> {rc}")
+    return succ, cost.value
+
+
+def tour_cost_xy(xy, kind, succ):
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    return lib().orc_tour_cost_xy(xy, len(xy) // 2, kind, np.ascontiguousarray(succ, np.int32))
+
+
+def two_opt_once_xy(xy, kind, succ, cost):
+    """In-place on succ.  Returns (delta, new_cost, (a, b))."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    cc = C.c_double(cost)
+    mv = np.empty(2, dtype=np.int32)
+    d = lib().orc_two_opt_once_xy(xy, len(xy) // 2, kind, succ, C.byref(cc), mv)
+    return d, cc.value, (int(mv[0]), int(mv[1]))
 
 
 def valid_tour(succ):

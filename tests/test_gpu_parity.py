@@ -399,3 +399,89 @@ def test_vns_with_host_kicks(eng, T, O, instances, golden):
             for _ in range(r):
                 O.vns_kick(succ)
         assert (best_cost, fx(O, best)) == (g["cost"], g["fnv"])
+
+
+# ------------------------------------------------------------------ matrix-free mode
+@pytest.fixture
+def mf(eng, T):
+    eng.set_option(T.OPT_MATRIX_FREE, 1)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+    yield eng
+    eng.set_option(T.OPT_MATRIX_FREE, 0)
+
+
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123"])
+def test_matrix_free_golden(mf, T, O, instances, golden, name):
+    """weights recomputed from coordinates in every kernel: same NN tour, same 2-opt trajectory"""
+    xy, c = instances(name)
+    mf.set_points(xy); mf.build_costs()
+    assert mf.info()["matrix_free"] == 1
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    succ, nn_cost = mf.nn_tour(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    mf.set_option(T.OPT_HISTORY, 64)
+    cost, sweeps, _ = mf.two_opt(succ)
+    assert mf.info()["kernel"] == 4
+    assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+    a, b, d = mf.history(64)
+    run = nn_cost
+    for i, want in enumerate(g["trace"]):
+        run += d[i]
+        assert run == want
+    mf.set_option(T.OPT_HISTORY, 0)
+    with pytest.raises(T.TspGpuError):
+        mf.get_costs()                      # nothing to hand out
+
+
+def test_matrix_free_tabu_and_att(mf, T, O, instances, golden):
+    for case in golden["tabu_move"][:2]:
+        xy, c = instances(case["instance"])
+        mf.set_points(xy); mf.build_costs()
+        succ, cost = O.nn_tour(c, 0)
+        tl = np.full(len(xy), -1, dtype=np.int32)
+        for it, want in enumerate(case["steps"]):
+            cost = mf.tabu_move(succ, cost, tl, case["tenure"], it)
+            assert (cost, fx(O, succ), fx(O, tl)) == (want["cost"], want["fnv"], want["tabu_fnv"])
+    xy, _ = O.read_tsplib(data_path("att48"))
+    c = O.cost_matrix(xy, O.ATT)
+    mf.set_points(xy, O.ATT); mf.build_costs()
+    res = mf.multistart_nn_2opt()
+    want = O.multistart_nn_2opt(c)
+    assert (res["cost"], res["start"]) == (want[1], want[2]) and np.array_equal(res["path"], want[0])
+
+
+def test_matrix_free_d18512(mf, T, O, golden):
+    xy, _ = O.read_tsplib(data_path("d18512"))
+    mf.set_points(xy); mf.build_costs()
+    g = golden["instances"]["d18512"]["two_opt"]
+    mf.tour_nn(0, 0)
+    succ, nn_cost, _ = mf.tour_store(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    sweeps, _ = mf.tour_two_opt(0, max_sweeps=5)
+    succ, cost, _ = mf.tour_store(0)
+    assert (sweeps, cost, fx(O, succ)) == (5, g["final_cost"], g["final_fnv"])
+
+
+def test_pla85900_config5(eng, T, O):
+    """BASELINE config 5: pla85900, CEIL_2D, n = 85 900 -- a matrix row (343 KB) cannot sit in
+    LDS, the engine switches to matrix-free mode by itself.  The reference cannot run this
+    instance (CEIL_2D rejected, int overflow): pinned to the oracle's matrix-free restatement
+    (tests/golden/golden_large.json, TSPLIB CEIL_2D)."""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_large.json")))["pla85900"]
+    xy, ewt = O.read_tsplib(data_path("pla85900"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+    eng.set_points(xy, O.CEIL_2D); eng.build_costs()
+    assert eng.info()["matrix_free"] == 1 and eng.n == g["n"]
+    eng.tour_nn(0, 0)
+    succ, nn_cost, _ = eng.tour_store(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    eng.set_option(T.OPT_HISTORY, 8)
+    sweeps, _ = eng.tour_two_opt(0, max_sweeps=len(g["moves"]))
+    a, b, d = eng.history(8)
+    succ, cost, _ = eng.tour_store(0)
+    eng.set_option(T.OPT_HISTORY, 0)
+    for i, m in enumerate(g["moves"]):
+        assert (int(a[i]), int(b[i]), float(d[i])) == (m["a"], m["b"], m["delta"])
+    assert cost == g["moves"][-1]["cost"] and fx(O, succ) == g["moves"][-1]["fnv"]
+    assert O.valid_tour(succ)

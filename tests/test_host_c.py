@@ -153,3 +153,16 @@ def test_binary_rejects_att_like_the_reference():
     assert rc == 1                                           # tsp.c:576-584
     rc, out, err = run_q("-f", os.path.join(DATA, "att48.tsp"), "-alg", "2OPT_GREEDY", env={"TSP_ALLOW_EXT": "1"})
     assert rc == 0 and float(out.split(":")[1]) >= 10628    # TSPLIB optimum of att48 as a bound
+
+
+@pytest.mark.gpu
+def test_binary_matrix_free_pla85900():
+    """config 5 through the reference's CLI: 85 900 nodes, CEIL_2D, no n x n matrix anywhere
+    (59 GB in the reference's format, which also overflows its int indices)"""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))["pla85900"]
+    rc, out, err = run_q("-f", os.path.join(DATA, "pla85900.tsp"), "-alg", "GREEDY", env={"TSP_ALLOW_EXT": "1"})
+    assert rc == 0 and out == "Cost: %.2f" % g["nn_cost"], err
+    # and on a small instance the matrix-free binary equals the matrix binary
+    rc, out, err = run_q("-f", os.path.join(DATA, "kroA100.tsp"), "-alg", "2OPT_GREEDY", env={"TSP_MATRIX_FREE": "1"})
+    assert rc == 0 and out == "Cost: 21360.00", err

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Matrix-free sweep rate: python tools/otf_rate.py [instance|nNNNN] [kind]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import travellingsalesmanoptimization_amd as T
+from travellingsalesmanoptimization_amd import tsplib
+from bench import reference_points
+what = sys.argv[1] if len(sys.argv) > 1 else "pla85900"
+if what.startswith("n") and what[1:].isdigit():
+    xy, kind = reference_points(int(what[1:]), 123), T.EUC_2D
+else:
+    xy, kind = tsplib.read(os.path.join(ROOT, "tests", "golden", "data", what + ".tsp"))
+n = len(xy)
+for mf in (1, 0):
+    eng = T.Engine(0)
+    eng.set_option(T.OPT_MATRIX_FREE, mf)
+    eng.set_points(xy, kind)
+    try:
+        eng.build_costs()
+        eng.tour_nn(0, 0)
+        reps = 20 if n < 20000 else 3
+        ms = eng.time_sweep(0, reps)
+        i = eng.info()
+        print(f"{what} n={n} matrix_free={i['matrix_free']} kernel={i['kernel']} elem={i['elem']} wgs={i['wgs_per_tour']}: "
+              f"{ms*1e3:10.1f} us / sweep  {T.evals_per_sweep(n)/ms/1e6:8.1f} Gevals/s", flush=True)
+    except T.TspGpuError as e:
+        print(f"{what} n={n} matrix_free={mf}: {e}", flush=True)
+    eng.close()

@@ -174,6 +174,17 @@ __device__ __forceinline__ double edge_weight(double ax, double ay, double bx, d
     return __builtin_ceil(__builtin_sqrt(sq)); // CEIL_2D
 }
 
+// one matrix cell, from the resident matrix or -- matrix-free mode, mat == nullptr -- recomputed
+// from the coordinates with the very same arithmetic
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::acc cell(const T *mat, const double2 *pts, int kind, int ld, int u, int v)
+{
+    typedef typename Elem<T>::acc AT;
+    if (mat) return (AT)mat[(size_t)u * ld + v];
+    const double2 pu = pts[u], pv = pts[v];
+    return (AT)edge_weight(pu.x, pu.y, pv.x, pv.y, kind);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__ pts, int n, int ld, int kind,
                                                      T *__restrict__ out)
@@ -259,7 +270,8 @@ struct Tours {
     double *dpos, *dnb;      // [cap][n] 8-byte slots; integer modes use the first 4n bytes of each
     double *cost, *last_delta; // [cap]
     int *dir, *done, *nsweeps, *cap_sweeps, *status; // [cap]
-    Partial *partial;        // [cap][MAX_WGS_PER_TOUR]
+    Partial *partial;        // [cap][pstride]
+    int pstride;             // partial slots per tour (>= workgroups per tour of any sweep)
 };
 
 struct TabuState {           // device-resident, slot 0 only
@@ -290,7 +302,7 @@ __device__ __forceinline__ int wrap(int p, int n) { return p < 0 ? p + n : (p >=
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict__ mat, int n, int ld, int slot0,
-                                                    const int *__restrict__ caps)
+                                                    const int *__restrict__ caps, const double2 *__restrict__ pts, int kind)
 {
     __shared__ double chunk[1024];
     typedef typename Elem<T>::acc AT;
@@ -303,7 +315,7 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
         const int node = ord[p];
         const int s = ord[p + 1 == n ? 0 : p + 1];
-        const AT w = (AT)mat[(size_t)node * ld + s];
+        const AT w = cell<T>(mat, pts, kind, ld, node, s);
         pos[node] = p;
         dp[p] = w;
         succ[node] = s;
@@ -362,7 +374,7 @@ __global__ void __launch_bounds__(256) k_export_succ(Tours S, int n, int slot0)
 // ---------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat, int n, int ld, int slot0,
-                                             const int *__restrict__ starts)
+                                             const int *__restrict__ starts, const double2 *__restrict__ pts, int kind)
 {
     __shared__ Partial red[2][16];
     const int t = slot0 + blockIdx.x;
@@ -370,19 +382,23 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
     int *ord = S.ord + (size_t)t * n;
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nw = (BT + 63) >> 6;
-    u64 seen = 0; // bit k <-> node tid + k*BT
-    if (start % BT == tid) seen |= 1ull << (start / BT);
+    u64 seen = 0, seen_hi = 0; // bit k <-> node tid + k*BT (k < 128: n <= 128*BT)
+    if (start % BT == tid) { const int k = start / BT; if (k < 64) seen |= 1ull << k; else seen_hi |= 1ull << (k - 64); }
     int cur = start;
     double total = 0;
     if (tid == 0) ord[0] = start;
     int step = 1;
     for (; step < n; step++) {
         const T *row = mat + (size_t)cur * ld;
+        double2 pc = make_double2(0, 0);
+        if (!mat) pc = pts[cur];
         double lo = DBL_MAX;
         u64 arg = KEY_NONE;
         for (int k = 0, i = tid; i < n; i += BT, k++) {
-            if ((seen >> k) & 1) continue;
-            const double w = Elem<T>::widen(row[i]);
+            if (((k < 64 ? seen >> k : seen_hi >> (k - 64)) & 1)) continue;
+            double w;
+            if (mat) w = Elem<T>::widen(row[i]);
+            else { const double2 pi = pts[i]; w = i == cur ? -1.0 : edge_weight(pc.x, pc.y, pi.x, pi.y, kind); }
             if (w != -1.0 && w < lo) { lo = w; arg = (u64)i; } // NOT_CONNECTED, utils.h:35
         }
         for (int off = 32; off > 0; off >>= 1) {
@@ -398,12 +414,12 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
             if (key_better(r[w].d, r[w].key, lo, arg)) { lo = r[w].d; arg = r[w].key; }
         if (arg == KEY_NONE) break; // nothing reachable: heuristics.c:268-272 closes the path here
         const int nxt = (int)arg;
-        if (nxt % BT == tid) seen |= 1ull << (nxt / BT);
+        if (nxt % BT == tid) { const int k = nxt / BT; if (k < 64) seen |= 1ull << k; else seen_hi |= 1ull << (k - 64); }
         if (tid == 0) { ord[step] = nxt; total += lo; }
         cur = nxt;
     }
     if (tid == 0) {
-        total += Elem<T>::widen(mat[(size_t)cur * ld + start]); // heuristics.c:281
+        total += mat ? Elem<T>::widen(mat[(size_t)cur * ld + start]) : (double)cell<T>(mat, pts, kind, ld, cur, start); // heuristics.c:281
         S.cost[t] = total;
         S.status[t] = (step == n) ? 0 : 1; // 1: tour left incomplete
     }
@@ -419,6 +435,9 @@ struct SweepArgs {
     int symmetric;
     int ablate;              // diagnostics only: 1 = no pair evaluation, 2 = no row traffic (results are wrong)
     unsigned long long *stamps; // diagnostics only: 64 wall-clock stamps (10 ns ticks) per workgroup, or null
+    const double2 *pts;      // matrix-free mode: node coordinates, and
+    const double2 *spts;     //   spts[b] = coordinates of succ b (gathered once per sweep)
+    int kind;                //   edge-weight kind
     const int *tabu_list;    // TABU only
     const TabuState *tabu;   // TABU only
 };
@@ -524,7 +543,7 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
     }
 }
 
@@ -756,7 +775,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
     }
 }
 
@@ -995,10 +1014,145 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * MAX_WGS_PER_TOUR + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
     }
     STAMP(4);
 #undef STAMP
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-free ("on the fly") sweep: for instances whose matrix row does not fit LDS or whose
+// n x n matrix should not be built at all (BASELINE config 5: pla85900, 59 GB of doubles in the
+// reference's format).  Every c[i][j] is recomputed from the coordinates with the arithmetic
+// of k_build_costs, so the trajectory is the matrix trajectory.
+//
+// Workgroup g owns RUN consecutive tour edges (a_t, a_t+1); the RUN+1 points of its nodes sit
+// in LDS (broadcast reads).  A thread streams over b with coalesced loads of four per-node
+// arrays -- P_b, P_succ(b) (gathered once per sweep by k_gather_spts), c[b][succ b], pos[b] --
+// and evaluates pair (a_t, b) for every t whose ownership range contains b:
+//     delta = w(P_a_t, P_b) + w(P_a_t+1, P_succ b) - (c[a_t][a_t+1] + c[b][succ b]).
+// The per-b data is read once per RUN pairs; there is no n^2 operand, so the HBM roofline
+// does not apply: the bound is VALU issue (two edge weights = two f64 squared lengths and two
+// correctly rounded roots per pair).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gather_spts(Tours S, int n, int slot0, const double2 *__restrict__ pts,
+                                                     double2 *__restrict__ spts)
+{
+    const int t = slot0 + blockIdx.y;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n || S.done[t]) return;
+    spts[(size_t)blockIdx.y * n + b] = pts[S.succ[(size_t)t * n + b]];
+}
+
+template <bool TABU>
+__global__ void __launch_bounds__(256) k_sweep_otf(SweepArgs A)
+{
+    constexpr int RUN = 8;
+    __shared__ int nodes_s[RUN + 2];
+    __shared__ double2 npt[RUN + 1];
+    __shared__ int dstep[RUN];
+    __shared__ Partial scratch[16];
+    const int n = A.n;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int *ord = A.S.ord + (size_t)t * n;
+    const int *pos = A.S.pos + (size_t)t * n;
+    const int *succ = A.S.succ + (size_t)t * n;
+    const int *dnb = dnb_of<int>(A.S, t, n);
+    const double2 *pts = A.pts;
+    const double2 *spts = A.spts + (size_t)blockIdx.y * n;
+    const int dir = A.S.dir[t];
+    const int kind = A.kind;
+    int *nodes = nodes_s + 1;
+
+    int iter = 0, tenure = 0;
+    if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
+
+    const int p0 = blockIdx.x * RUN;
+    const int cnt = min(RUN, n - p0);
+    if (tid <= cnt + 1) {
+        const int i = tid - 1;
+        const int v = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+        nodes[i] = v;
+        if (i >= 0) npt[i] = pts[v];
+        if (i >= 0 && i < cnt) dstep[i] = dnb[v];      // c[a_i][succ a_i]
+    }
+    __syncthreads();
+
+    const int BIG = 1 << 29;
+    int best_d = TABU ? INT_MAX : 0;
+    int best_a = 0, best_b = 0;
+    bool have = false;
+    const int wave_lane0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+
+    for (int base = 0; base < n; base += BT) {
+        const int b = base + tid;
+        const bool inb = b < n;
+        const int bb = inb ? b : n - 1;
+        const double2 pb = pts[bb];
+        const double2 sp = spts[bb];
+        int dn = dnb[bb];
+        const int qb = pos[bb];
+        if constexpr (TABU) {
+            if (inb && (is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, succ[bb], iter, tenure))) dn = -BIG;
+        }
+        if (!inb) dn = -BIG;
+        int j = dir > 0 ? qb - p0 : p0 + cnt - qb;       // run index of b, if it is a node of this run
+        if (j < -1) j += n;
+        if (j > n - 2) j -= n;
+        const int jl = ((j >= -1 && j <= cnt) ? j : 1 << 20) - 1;
+        const int w0 = base + wave_lane0;                // this wave's first b
+        if (w0 >= n) continue;
+#pragma unroll
+        for (int s = 0; s < RUN; s++) {
+            if (s >= cnt) break;
+            const int a = nodes[s];
+            if constexpr (TABU) {
+                if (is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, nodes[s + 1], iter, tenure)) continue;
+            }
+            const int lo = a + 1 == n ? 0 : a + 1;
+            const int len = (n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1);
+            int t0 = w0 - lo;
+            if (t0 < 0) t0 += n;
+            const bool nowrap = t0 + 64 <= n && w0 + 64 <= n;
+            if (nowrap && t0 >= len) continue;           // wave entirely outside a's share
+            bool ok = (unsigned)(s - jl) > 2u;           // not b in {pred a, a, succ a}
+            if (!(nowrap && t0 + 64 <= len)) {
+                int tt = b - lo;
+                tt += (tt >> 31) & n;
+                ok &= (unsigned)tt < (unsigned)len;
+            }
+            const double2 pa = npt[s], ps = npt[s + 1];
+            const int made = (int)edge_weight(pa.x, pa.y, pb.x, pb.y, kind) + (int)edge_weight(ps.x, ps.y, sp.x, sp.y, kind);
+            const int delta = made - (dstep[s] + dn);
+            const bool lt = ok & (delta < best_d);
+            bool eq = ok & (delta == best_d);
+            if constexpr (!TABU) eq &= delta < 0;
+            if (__ballot(eq)) {
+                if (eq) {
+                    const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                    const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                   : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                    if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                }
+            }
+            best_d = lt ? delta : best_d;
+            best_a = lt ? a : best_a;
+            best_b = lt ? b : best_b;
+            have = have | lt;
+        }
+    }
+    double d = (double)best_d;
+    u64 key;
+    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    __syncthreads();
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1014,6 +1168,8 @@ struct ApplyArgs {
     Tours S;
     const void *mat;
     int n, ld, slot0, G, symmetric;
+    const double2 *pts;  // matrix-free mode (mat == nullptr)
+    int kind;
     int *tabu_list;      // TABU
     TabuState *tabu;     // TABU
     int *best_succ;      // TABU resident incumbent
@@ -1033,7 +1189,7 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
 
     double d = TABU ? DBL_MAX : 0.0;
     u64 key = TABU ? KEY_NONE : 0;
-    const Partial *part = A.S.partial + (size_t)t * MAX_WGS_PER_TOUR;
+    const Partial *part = A.S.partial + (size_t)t * A.S.pstride;
     for (int g = tid; g < A.G; g += BT) {
         const Partial q = part[g];
         if (key_better(q.d, q.key, d, key)) { d = q.d; key = q.key; }
@@ -1094,7 +1250,7 @@ __global__ void __launch_bounds__(1024) k_apply(ApplyArgs A)
                 }
             }
             // the two new edges {a,b} and {succ a, succ b}: they are also the arc's boundary cells
-            const AT wA = (AT)mat[(size_t)x0 * ld + x2], wB = (AT)mat[(size_t)x1 * ld + x3];
+            const AT wA = cell<T>(mat, A.pts, A.kind, ld, x0, x2), wB = cell<T>(mat, A.pts, A.kind, ld, x1, x3);
             const bool a_in_A = x0 == a || x2 == a;
             __syncthreads(); // every read of the old ord/dpos is complete
             // cells: swap k <-> M-1-k ; inner edges (M-1 of them): swap k <-> M-2-k
@@ -1224,7 +1380,10 @@ struct tspgpu_ctx {
     bool have_points = false, have_costs = false, symmetric = true;
     int elem = 0; // TSPGPU_ELEM_F64 / _I32 / _U16 in use
     double2 *d_pts = nullptr;
-    void *d_mat = nullptr;   // [n][ld] cells of the kind in `elem`
+    void *d_mat = nullptr;   // [n][ld] cells of the kind in `elem`; nullptr in matrix-free mode
+    bool otf = false;        // matrix-free: weights recomputed from d_pts
+    int opt_otf = 0;         // 0 auto, 1 force matrix-free, 2 never
+    double2 *d_spts = nullptr; size_t spts_cap = 0;
     double cost_bound = 0;   // upper bound of any entry the uploaded points can produce
     int *d_flags = nullptr;
 
@@ -1325,7 +1484,8 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
     HIP_TRY(hipMalloc(&S.nsweeps, T * 4));
     HIP_TRY(hipMalloc(&S.cap_sweeps, T * 4));
     HIP_TRY(hipMalloc(&S.status, T * 4));
-    HIP_TRY(hipMalloc(&S.partial, T * MAX_WGS_PER_TOUR * sizeof(Partial)));
+    S.pstride = std::max(MAX_WGS_PER_TOUR, (n + 7) / 8 + 8); // the matrix-free sweep runs n/8 workgroups per tour
+    HIP_TRY(hipMalloc(&S.partial, T * (size_t)S.pstride * sizeof(Partial)));
     HIP_TRY(hipMalloc(&ctx->d_starts, T * 4));
     HIP_TRY(hipMalloc(&ctx->d_caps, T * 4));
     HIP_TRY(hipMalloc(&ctx->d_tabu_list, N * 4));
@@ -1343,7 +1503,7 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
 static int new_instance(tspgpu_ctx *ctx, int n)
 {
     if (n < 4) return fail(ctx, E_INVALID, "need at least 4 nodes, got %d", n);
-    if (n > 65535 * 64) return fail(ctx, E_INVALID, "n too large");
+    if (n > 131072) return fail(ctx, E_INVALID, "n = %d: at most 131072 nodes", n);
     free_matrix(ctx);
     free_tours(ctx);
     ctx->n = n;
@@ -1447,6 +1607,20 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         G = (n + P - 1) / P;
     };
     int G = 1, P = n;
+    if (ctx->otf) {
+        // matrix-free: 8 tour edges per workgroup, the whole b range per workgroup
+        if (ctx->spts_cap < (size_t)ntours * n) {
+            if (ctx->d_spts) hipFree(ctx->d_spts);
+            ctx->d_spts = nullptr; ctx->spts_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->d_spts, (size_t)ntours * n * sizeof(double2)));
+            ctx->spts_cap = (size_t)ntours * n;
+        }
+        P = 8; G = (n + P - 1) / P;
+        if (G > ctx->S.pstride) return fail(ctx, E_INTERNAL, "partial stride %d < %d workgroups", ctx->S.pstride, G);
+        ctx->plan_kernel = 4; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = 256; ctx->plan_NCH = 0; ctx->plan_D = 0;
+        ctx->plan_T = ntours; ctx->plan_lds = 0;
+        return E_OK;
+    }
     if (ctx->elem == TSPGPU_ELEM_U16 && kernel == 2) return fail(ctx, E_INVALID, "the pipelined sweep has no uint16 variant");
     // resident sweep: all P+1 (<= 9) rows of a run in LDS at once.  One chunk per thread for
     // uint16 (two would spill), at most two otherwise.
@@ -1524,7 +1698,17 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
     A.symmetric = ctx->symmetric ? 1 : 0;
     A.ablate = ctx->opt_ablate;
     A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
+    A.pts = ctx->d_pts; A.spts = ctx->d_spts; A.kind = ctx->kind;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
+    if (ctx->plan_kernel == 4) {
+        const int n = ctx->n;
+        hipLaunchKernelGGL(k_gather_spts, dim3((n + 255) / 256, ntours), dim3(256), 0, ctx->stream, ctx->S, n, slot0, ctx->d_pts, ctx->d_spts);
+        HIP_TRY(hipGetLastError());
+        const void *fo = tabu ? (const void *)k_sweep_otf<true> : (const void *)k_sweep_otf<false>;
+        void *ao[] = {&A};
+        HIP_TRY(hipLaunchKernel(fo, dim3(ctx->plan_G, ntours), dim3(256), ao, 0, ctx->stream));
+        return E_OK;
+    }
     const void *fn = ctx->plan_kernel == 3 ? res_kernel(ctx->elem, ctx->plan_NCH, tabu)
                    : ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
     void *args[] = {&A};
@@ -1539,6 +1723,7 @@ static int launch_apply(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, bool 
     A.mat = ctx->d_mat;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.G = ctx->plan_G;
     A.symmetric = ctx->symmetric ? 1 : 0;
+    A.pts = ctx->d_pts; A.kind = ctx->kind;
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
     A.best_succ = ctx->d_best_succ; A.trace = resident_tabu ? ctx->d_trace : nullptr;
     A.hist = ctx->hist;
@@ -1657,7 +1842,7 @@ static int init_slots(tspgpu_ctx *ctx, int slot0, int ntours, int cap)
     }
     const int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
     ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_tour_init<T>), dim3(ntours), dim3(BT), 0, ctx->stream, ctx->S,
-                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, caps));
+                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, caps, ctx->d_pts, ctx->kind));
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
@@ -1698,10 +1883,10 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
     HIP_TRY(hipMemcpyAsync(ctx->d_starts, h_starts, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
-    while ((long)BT * 64 < n) BT *= 2; // register visited mask: n <= 64*BT
-    if (BT > 1024) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 65536");
+    while ((long)BT * 128 < n && BT < 1024) BT *= 2; // register visited mask: n <= 128*BT
+    if ((long)BT * 128 < n) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 131072");
     ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
-                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts));
+                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts, ctx->d_pts, ctx->kind));
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
@@ -1756,6 +1941,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_flags) hipFree(ctx->d_flags);
     if (ctx->d_trace) hipFree(ctx->d_trace);
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
+    if (ctx->d_spts) hipFree(ctx->d_spts);
     if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); }
     for (auto e : ctx->ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -1795,6 +1981,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
         if (value && !ctx->d_stamps) HIP_TRY(hipMalloc(&ctx->d_stamps, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
         if (value) HIP_TRY(hipMemset(ctx->d_stamps, 0, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
         break;
+    case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
@@ -1815,6 +2002,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 7: return ctx->symmetric ? 1 : 0;
     case 8: return ctx->cus;
     case 9: return ctx->plan_D;
+    case 10: return ctx->otf ? 1 : 0;
     }
     return -1;
 }
@@ -1867,6 +2055,20 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
     if (ctx->opt_elem == TSPGPU_ELEM_I32 && !fits32) return fail(ctx, E_INVALID, "int32 storage requested but costs may reach %.0f", ctx->cost_bound);
     if (ctx->opt_elem != TSPGPU_ELEM_AUTO) ctx->elem = ctx->opt_elem;
     else ctx->elem = fits16 ? TSPGPU_ELEM_U16 : fits32 ? TSPGPU_ELEM_I32 : TSPGPU_ELEM_F64;
+    // matrix-free when asked for, or when one matrix row cannot sit in LDS (every matrix sweep
+    // gathers c[succ a][succ b] from an LDS row) -- e.g. pla85900: 343 KB per int32 row
+    const bool row_fits = (size_t)ctx->ld * elem_size(ctx->elem) + 2048 <= ctx->lds_max;
+    ctx->otf = ctx->opt_otf == 1 || (ctx->opt_otf == 0 && !row_fits);
+    if (ctx->otf) {
+        if (!fits32) return fail(ctx, E_EXHAUSTED, "matrix-free mode needs integer costs below 2^27 (bound %.0f)", ctx->cost_bound);
+        if (host_out) return fail(ctx, E_INVALID, "matrix-free mode: there is no n x n matrix to copy out (n = %d)", ctx->n);
+        ctx->elem = TSPGPU_ELEM_I32;   // integer deltas; no cells are stored
+        ctx->symmetric = true;
+        ctx->have_costs = true;
+        ctx->plan_kernel = 0;
+        return E_OK;
+    }
+    if (!row_fits) return fail(ctx, E_EXHAUSTED, "n = %d: a matrix row does not fit LDS and matrix-free mode is disabled", ctx->n);
     HIP_TRY(hipMalloc(&ctx->d_mat, cells * elem_size(ctx->elem)));
     int rc = launch_build(ctx);
     if (rc) return rc;
@@ -1888,6 +2090,7 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
     } else {
         free_matrix(ctx);
     }
+    ctx->otf = false;
     const int ld = ctx->ld;
     const size_t cells = (size_t)n * ld;
     double *stage = nullptr;
@@ -1931,6 +2134,7 @@ int tspgpu_get_costs(tspgpu_ctx *ctx, double *host_out)
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
+    if (ctx->otf) return fail(ctx, E_PRECOND, "matrix-free mode: no matrix is held");
     const int n = ctx->n, ld = ctx->ld;
     const double *src = (const double *)ctx->d_mat;
     double *tmp = nullptr;
@@ -2222,6 +2426,7 @@ int tspgpu_time_build(tspgpu_ctx *ctx, int reps, float *ms_mean)
     int rc = need_costs(ctx);
     if (rc) return rc;
     if (!ctx->have_points) return fail(ctx, E_PRECOND, "no points");
+    if (ctx->otf) { *ms_mean = 0; return E_OK; }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     if ((rc = launch_build(ctx))) return rc;

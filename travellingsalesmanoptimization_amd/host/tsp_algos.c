@@ -65,7 +65,8 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
     if (past_deadline()) {
         /* the reference recomputes the cost and leaves at the first poll */
         double c = 0;
-        for (int i = 0; i < tsp_inst.nnodes; i++) c += costs[(size_t)i * tsp_inst.nnodes + solution->path[i]];
+        for (int i = 0; i < tsp_inst.nnodes; i++)
+            c += costs ? costs[(size_t)i * tsp_inst.nnodes + solution->path[i]] : tsp_get_cost(i, solution->path[i]);
         solution->cost = c;
         log_debug("time limit exceeded in 2opt");
         e = DEADLINE_EXCEEDED;
@@ -115,7 +116,7 @@ void ref_reverse_path(int a, int succ_a, int b, int succ_b, int *prev, int *path
 /* heuristics.c:216-288 */
 ERROR_CODE h_greedyutil(int starting_node, tsp_solution *solution, double *costs)
 {
-    if (!costs) { log_error("matrix of costs not found"); return INTERNAL; }
+    if (!costs && !tsp_matrix_free) { log_error("matrix of costs not found"); return INTERNAL; }
     if (starting_node >= tsp_inst.nnodes || starting_node < 0) { log_error("starting node not correct"); return UNAVAILABLE; }
     if (past_deadline()) { log_warn("time limit exceeded in greedy util"); return DEADLINE_EXCEEDED; }
     tspgpu_ctx *g = ctx_for(costs, false);

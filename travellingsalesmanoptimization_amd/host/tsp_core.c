@@ -15,6 +15,7 @@
 instance tsp_inst;
 options tsp_env;
 int tsp_edge_weight_kind = TSPGPU_EUC_2D;
+bool tsp_matrix_free = false;
 
 static struct tspgpu_ctx *g_ctx = NULL;
 
@@ -139,6 +140,19 @@ ERROR_CODE tsp_compute_costs(void)
     int rc = tspgpu_set_points(g, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind);
     if (rc) { log_error("tspgpu_set_points: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
     free(tsp_inst.costs);
+    tsp_inst.costs = NULL;
+    /* Matrix-free above 32 768 nodes (8 GB of doubles on the host; the reference overflows int
+     * past 46 340 and needs 59 GB for pla85900) or on request: no n x n array anywhere, the
+     * device recomputes weights from the coordinates and tsp_inst.costs stays NULL. */
+    const char *mf = getenv("TSP_MATRIX_FREE");
+    tsp_matrix_free = (mf && atoi(mf) != 0) || n > 32768;
+    if (tsp_matrix_free) {
+        tspgpu_set_option(g, TSPGPU_OPT_MATRIX_FREE, 1);
+        rc = tspgpu_build_costs(g, NULL);
+        if (rc) { log_error("tspgpu_build_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
+        return T_OK;
+    }
+    tspgpu_set_option(g, TSPGPU_OPT_MATRIX_FREE, 0);
     tsp_inst.costs = (double *)malloc(n * n * sizeof(double)); /* size_t: no int overflow past n = 46340 */
     if (!tsp_inst.costs) return RESOURCE_EXHAUSTED;
     rc = tspgpu_build_costs(g, tsp_inst.costs);
@@ -146,7 +160,21 @@ ERROR_CODE tsp_compute_costs(void)
     return T_OK;
 }
 
-double tsp_get_cost(int i, int j) { return tsp_inst.costs[(size_t)i * tsp_inst.nnodes + j]; }
+/* one weight on the host with the arithmetic of tsp.c:629 (and TSPLIB's for ATT / CEIL_2D) */
+static double host_weight(int i, int j)
+{
+    if (i == j) return -1.0;
+    const double dx = tsp_inst.points[j].x - tsp_inst.points[i].x, dy = tsp_inst.points[j].y - tsp_inst.points[i].y;
+    const double sq = dx * dx + dy * dy;
+    if (tsp_edge_weight_kind == TSPGPU_EUC_2D) return (double)((int)(sqrtf((float)sq) + 0.5));
+    if (tsp_edge_weight_kind == TSPGPU_ATT) { const double r = sqrt(sq / 10.0), t = (double)(long)(r + 0.5); return t < r ? t + 1.0 : t; }
+    return ceil(sqrt(sq));
+}
+
+double tsp_get_cost(int i, int j)
+{
+    return tsp_inst.costs ? tsp_inst.costs[(size_t)i * tsp_inst.nnodes + j] : host_weight(i, j);
+}
 
 /* tsp.c:687-728 */
 bool tsp_is_tour(int path[], int n)

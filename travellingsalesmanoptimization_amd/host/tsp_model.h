@@ -162,6 +162,9 @@ ERROR_CODE tsp_run_algorithm(void);                          /* main.c:4-87 (heu
 /* edge-weight kind read from the TSPLIB header: 0 EUC_2D, 1 ATT, 2 CEIL_2D.  The reference
  * accepts EUC_2D only (tsp.c:576-584); the others are enabled by TSP_ALLOW_EXT=1. */
 extern int tsp_edge_weight_kind;
+/* true when no n x n matrix exists (n > 32 768 or TSP_MATRIX_FREE=1): tsp_inst.costs == NULL,
+ * tsp_get_cost recomputes, the device runs its matrix-free kernels */
+extern bool tsp_matrix_free;
 /* the device context behind tsp_inst.costs (created on first use; NULL if no MI355X) */
 struct tspgpu_ctx;
 struct tspgpu_ctx *tsp_gpu(void);
