@@ -55,6 +55,8 @@ enum {
     TSPGPU_OPT_BLOCK = 8,       /* threads per sweep workgroup (0 = auto) */
     TSPGPU_OPT_MAX_TOURS = 9,   /* tours kept in flight by the multi-start driver */
     TSPGPU_OPT_DEPTH = 10,      /* matrix rows in flight per workgroup in the pipelined sweep (0 = auto) */
+    TSPGPU_OPT_FUSED = 12,      /* one launch per sweep (resident kernel): 1 (default) when <= 4 tours are in flight,
+                                   2 always, 0 never (separate sweep + apply launches) */
     TSPGPU_OPT_MATRIX_FREE = 11 /* 0 auto (matrix-free when a matrix row cannot sit in LDS), 1 always, 2 never;
                                    takes effect at the next tspgpu_build_costs */
 };
@@ -67,7 +69,7 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
 /* info: 0 n, 1 row stride, 2 element kind in use, 3 sweep kernel in use,
  * 4 workgroups per tour, 5 LDS bytes per workgroup, 6 threads per workgroup,
  * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup,
- * 10 matrix-free mode in use */
+ * 10 matrix-free mode in use, 11 one-launch-per-sweep path in use */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

@@ -126,10 +126,20 @@ def test_nn_all_golden(eng, T, O, instances, golden):
 
 
 # ------------------------------------------------------------------ K2/K4 sweeps
+@pytest.fixture(params=[2, 0], ids=["fused", "split"])
+def fused(request, eng, T):
+    """one launch per sweep (k_sweep_fused) vs. separate sweep + apply launches"""
+    eng.set_option(T.OPT_FUSED, request.param)
+    yield request.param
+    eng.set_option(T.OPT_FUSED, 1)
+
+
 @pytest.mark.parametrize("elem,kernel", COMBOS)
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "n64_s7", "n200_s3"])
-def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel):
+def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel, fused):
     """every sweep picks the reference's (a,b) and leaves the reference's tour"""
+    if fused and kernel != 3:
+        pytest.skip("the fused path exists for the resident kernel only")
     xy, c = setup(eng, T, O, instances, name, elem, kernel)
     succ, cost = O.nn_tour(c, 0)
     g = succ.copy(); gcost = cost
@@ -144,7 +154,9 @@ def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel):
 
 @pytest.mark.parametrize("elem,kernel", COMBOS)
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123", "n1024_s1"])
-def test_two_opt_to_local_optimum_golden(eng, T, O, instances, golden, name, elem, kernel):
+def test_two_opt_to_local_optimum_golden(eng, T, O, instances, golden, name, elem, kernel, fused):
+    if fused and kernel != 3:
+        pytest.skip("the fused path exists for the resident kernel only")
     xy, c = setup(eng, T, O, instances, name, elem, kernel)
     g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
     succ, nn_cost = eng.nn_tour(0)
@@ -191,7 +203,9 @@ def test_full_size_fnl4461(eng, T, O, golden, elem):
 
 
 @pytest.mark.parametrize("elem,kernel", [(0, 0), (1, 0), (2, 0), (2, 1), (2, 3), (3, 0), (3, 1)])
-def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel):
+def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
+    if fused and kernel not in (0, 3):
+        pytest.skip("the fused path exists for the resident kernel only")
     """the configuration BASELINE.json's metric is quoted on: -n 4096 -seed 123, NN(0) then
     609 sweeps to 488522 (reference: 48.7 s on one core)"""
     g = golden["random"]["n4096_s123"]
@@ -336,12 +350,14 @@ def test_multistart_subset_and_chunks(eng, T, O, instances):
     xy, c = setup(eng, T, O, instances, "n200_s3", 0)
     starts = np.array([7, 199, 0, 33, 34, 150, 3], dtype=np.int32)
     want = O.multistart_nn_2opt(c, starts)
-    for cap in (1024, 3):
+    for cap, fused_mode in ((1024, 1), (3, 1), (1024, 2), (1024, 0)):
         eng.set_option(T.OPT_MAX_TOURS, cap)
+        eng.set_option(T.OPT_FUSED, fused_mode)
         res = eng.multistart_nn_2opt(starts)
         assert (res["cost"], res["start"], res["sweeps"]) == (want[1], want[2], want[3])
         assert np.array_equal(res["path"], want[0])
     eng.set_option(T.OPT_MAX_TOURS, 1024)
+    eng.set_option(T.OPT_FUSED, 1)
 
 
 def test_deadline_returns_code_4_with_valid_tour(eng, T, O, instances):

@@ -281,6 +281,15 @@ struct TabuState {           // device-resident, slot 0 only
 
 struct HistBuf { int *a, *b; double *d; int cap; };
 
+struct Fused {               // ping-pong state of the one-launch-per-sweep path, [parity]
+    int *ord[2], *pos[2], *nl[2], *nr[2];   // [cap][n]
+    double *dl[2], *dr[2];                  // [cap][n] 8-byte slots
+    int *dir[2], *k[2], *stop[2];           // [cap]
+    double *cost[2];                        // [cap]
+    Partial *partial[2];                    // [cap][pstride]
+    int *cur;                               // [cap] parity holding the result once `done`
+};
+
 template <typename T>
 __device__ __forceinline__ T *dpos_of(const Tours &S, int t, int n)
 {
@@ -440,6 +449,9 @@ struct SweepArgs {
     int kind;                //   edge-weight kind
     const int *tabu_list;    // TABU only
     const TabuState *tabu;   // TABU only
+    Fused F;                 // fused path only
+    int parity;              //   this launch writes F.*[parity], reads F.*[1 - parity]
+    HistBuf hist;            //   slot 0 move history
 };
 
 // acceptance rule for the pair {a,b} seen from a's workgroup.  Symmetric
@@ -1020,6 +1032,381 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
 #undef STAMP
 }
 
+
+// ---------------------------------------------------------------------------
+// One launch per sweep ("fused"): k_sweep_fused = k_apply of the previous sweep's move +
+// k_sweep_res, for symmetric matrices.  The tour state is kept twice (parity ping-pong) in a
+// direction-free form -- ord/pos plus, per NODE, its two array neighbours (nl, nr) and the two
+// edge costs (dl, dr); succ b = dir > 0 ? nr : nl.  A 2-opt move reverses an array range: nodes
+// inside swap (nl,dl) <-> (nr,dr), four nodes around the ends get one new neighbour, positions
+// reflect.  So every workgroup derives everything it needs of the NEW state from coalesced
+// loads of the OLD one plus a handful of scalars (it reduces the previous launch's partials
+// itself), and the new state is written piecewise: each workgroup records its own slice of
+// nodes and its own cells of ord.  No separate apply launch, no gather, no inter-workgroup
+// communication inside a launch.  k_fused_begin / k_fused_end convert from / to the Tours form.
+// ---------------------------------------------------------------------------
+template <typename AT>
+__global__ void __launch_bounds__(256) k_fused_begin(Tours S, Fused F, int n, int slot0)
+{
+    const int t = slot0 + blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const size_t tn = (size_t)t * n;
+    if (p < n) {
+        const int *ord = S.ord + tn;
+        const AT *dp = reinterpret_cast<const AT *>(S.dpos + tn);
+        const int v = ord[p], pl = wrap(p - 1, n);
+        F.ord[1][tn + p] = v;
+        F.pos[1][tn + v] = p;
+        F.nl[1][tn + v] = ord[pl];
+        F.nr[1][tn + v] = ord[wrap(p + 1, n)];
+        reinterpret_cast<AT *>(F.dl[1] + tn)[v] = dp[pl];
+        reinterpret_cast<AT *>(F.dr[1] + tn)[v] = dp[p];
+    }
+    if (p == 0) {
+        F.dir[1][t] = S.dir[t]; F.k[1][t] = 0; F.cost[1][t] = S.cost[t]; F.stop[1][t] = 0; F.stop[0][t] = 0;
+        F.cur[t] = 1;
+    }
+}
+
+template <typename AT>
+__global__ void __launch_bounds__(256) k_fused_end(Tours S, Fused F, int n, int slot0, int last_parity)
+{
+    const int t = slot0 + blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    const size_t tn = (size_t)t * n;
+    const int c = S.done[t] ? F.cur[t] : last_parity;   // not finished (deadline): the last state written
+    const int dir = F.dir[c][t];
+    if (v < n) {
+        const int p = F.pos[c][tn + v];
+        const int l = F.nl[c][tn + v], r = F.nr[c][tn + v];
+        const AT dl = reinterpret_cast<const AT *>(F.dl[c] + tn)[v], dr = reinterpret_cast<const AT *>(F.dr[c] + tn)[v];
+        S.ord[tn + p] = v;
+        S.pos[tn + v] = p;
+        reinterpret_cast<AT *>(S.dpos + tn)[p] = dr;
+        S.succ[tn + v] = dir > 0 ? r : l;
+        reinterpret_cast<AT *>(S.dnb + tn)[v] = dir > 0 ? dr : dl;
+    }
+    if (v == 0) { S.dir[t] = dir; S.cost[t] = F.cost[c][t]; }
+}
+
+template <typename T, int NCH, int PMAX>
+__global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
+{
+    typedef typename Elem<T>::vec VT;
+    typedef typename Elem<T>::acc AT;
+    constexpr int V = Elem<T>::V;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = A.n, ld = A.ld;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V;
+
+    // LDS: (P+1) rows | nodes[-1 .. P] | reduction scratch
+    T *rows = reinterpret_cast<T *>(smem);
+    const size_t rows_bytes = (size_t)(A.P + 1) * ld * sizeof(T);
+    int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
+    Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4);
+
+    constexpr bool TABU = false;
+    const T *mat = static_cast<const T *>(A.mat);
+    const int rd = 1 - A.parity, wr = A.parity;       // state read / written by this launch
+    const size_t tn = (size_t)t * n;
+    const int *ord_o = A.F.ord[rd] + tn, *pos_o = A.F.pos[rd] + tn;
+    const int *nl_o = A.F.nl[rd] + tn, *nr_o = A.F.nr[rd] + tn;
+    const AT *dl_o = reinterpret_cast<const AT *>(A.F.dl[rd] + tn), *dr_o = reinterpret_cast<const AT *>(A.F.dr[rd] + tn);
+    const int k_done = A.F.k[rd][t];                   // sweeps completed before this launch
+    const int dir_o = A.F.dir[rd][t];
+    const int cap = A.S.cap_sweeps[t];
+
+    unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
+#define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
+    STAMP(0);
+
+    // ---- the move found by the previous launch (every workgroup reduces the same partials)
+    double md = 0.0;
+    u64 mkey = 0;
+    if (k_done > 0) {
+        const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
+        for (int g = tid; g < (int)gridDim.x; g += BT) {
+            const Partial q = part[g];
+            if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; }
+        }
+        block_argmin(md, mkey, scratch);
+    }
+    const bool move = k_done > 0 && md < TWO_OPT_EPS;
+    if (A.F.stop[rd][t] || (k_done > 0 && !move)) {
+        // either the previous launch applied the last move a sweep cap allows, or the previous
+        // sweep was the final, non-improving one: the state that launch left is the result.
+        // (Every workgroup leaves here without writing, so a workgroup that starts after
+        // workgroup 0 has raised `done` behaves the same.)
+        if (blockIdx.x == 0 && tid == 0) {
+            A.S.done[t] = 1; A.F.cur[t] = rd; A.S.nsweeps[t] = k_done;
+            if (!A.F.stop[rd][t]) {
+                A.S.last_delta[t] = md;
+                if (t == 0 && k_done <= A.hist.cap) { A.hist.a[k_done - 1] = -1; A.hist.b[k_done - 1] = -1; A.hist.d[k_done - 1] = md; }
+            }
+        }
+        return;
+    }
+    const bool last = cap >= 0 && k_done >= cap;     // apply this move, then stop sweeping
+    const int ma = (int)(mkey >> 32), mb = (int)(mkey & 0xffffffffu);
+
+    // ---- the move as an array operation on the OLD state (see Tours): reverse cells [lo, lo+M-1]
+    int lo = 0, M = 0, ndir = dir_o;
+    int x0 = -1, x1 = -1, x2 = -1, x3 = -1;
+    AT wA = 0, wB = 0;
+    if (move) {
+        const int i = pos_o[ma], j = pos_o[mb];
+        int L = (j - i) * dir_o;
+        if (L < 0) L += n;
+        const bool other = n - L < L;
+        M = other ? n - L : L;
+        const int first = other ? wrap(j + dir_o, n) : wrap(i + dir_o, n);
+        lo = dir_o > 0 ? first : wrap(first - (M - 1), n);
+        if (other) ndir = -dir_o;
+        x0 = ord_o[wrap(lo - 1, n)]; x1 = ord_o[lo];
+        x2 = ord_o[wrap(lo + M - 1, n)]; x3 = ord_o[wrap(lo + M, n)];
+        wA = (AT)mat[(size_t)x0 * ld + x2];            // the two new edges {a,b}, {succ a, succ b}
+        wB = (AT)mat[(size_t)x1 * ld + x3];
+    }
+    auto new_cell = [&](int p) __attribute__((always_inline)) {   // old cell holding what cell p holds after the move
+        int r = p - lo;
+        if (r < 0) r += n;
+        return r < M ? wrap(lo + M - 1 - r, n) : p;
+    };
+
+    const int p0 = blockIdx.x * A.P;
+    const int cnt = min(A.P, n - p0);
+    // the run in TOUR order on the NEW state; this workgroup also writes its cells of the new ord
+    for (int i = tid - 1; i <= cnt; i += BT) {
+        const int p = wrap(p0 + (ndir > 0 ? i : cnt - i), n);
+        const int v = ord_o[new_cell(p)];
+        nodes[i] = v;
+        const int pi = ndir > 0 ? i : cnt - i;           // offset of p inside [p0, p0+cnt)
+        if (pi >= 0 && pi < cnt) A.F.ord[wr][tn + p] = v;
+    }
+
+    // per-thread state of the owned b's on the NEW state, from coalesced loads of the old one:
+    // a node inside the reversed range swaps its left/right neighbour (and edge cost); the four
+    // nodes around the range ends get one new neighbour.  No gather, no dependence on the move
+    // beyond scalars.  The workgroup that owns a slice of b's also writes their new records.
+    const AT BIG = Elem<T>::big();
+    int sboff[NCH][V], jb[NCH][V];
+    AT dnv[NCH][V];
+    const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int b0 = min((c * BT + tid) * V, ld - V);
+        int qv[V], lv[V], rv[V];
+        AT dlv[V], drv[V];
+        load_run<V>(pos_o + b0, qv);
+        load_run<V>(nl_o + b0, lv);
+        load_run<V>(nr_o + b0, rv);
+        load_run<V>(dl_o + b0, dlv);
+        load_run<V>(dr_o + b0, drv);
+        const int ub0 = (c * BT + tid) * V;
+        const bool mine = ub0 < n && ub0 / slice == (int)blockIdx.x;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            int r = qv[v] - lo;
+            if (r < 0) r += n;
+            const bool inr = r < M;
+            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[v];
+            int l2 = inr ? rv[v] : lv[v], r2 = inr ? lv[v] : rv[v];
+            AT dl2 = inr ? drv[v] : dlv[v], dr2 = inr ? dlv[v] : drv[v];
+            if (move) {
+                if (b == x0) { r2 = x2; dr2 = wA; }
+                if (b == x3) { l2 = x1; dl2 = wB; }
+                if (b == x1) { r2 = x3; dr2 = wB; }
+                if (b == x2) { l2 = x0; dl2 = wA; }
+            }
+            if (mine && b < n) {
+                A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
+                reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
+                reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
+            }
+            const int sb = b < n ? (ndir > 0 ? r2 : l2) : 0;
+            const AT dn = ndir > 0 ? dr2 : dl2;
+            sboff[c][v] = sb * (int)sizeof(T);
+            dnv[c][v] = b >= n ? -BIG : dn;  // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+            int j = ndir > 0 ? qn - p0 : p0 + cnt - qn;
+            if (j < -1) j += n;
+            if (j > n - 2) j -= n;
+            jb[c][v] = ((b < n && j >= -1 && j <= cnt) ? j : 1 << 20) - 1;   // invalid steps: jb .. jb+2
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0) {                   // per-tour scalars of the new state
+        const double cost_n = A.F.cost[rd][t] + (move ? md : 0.0);
+        A.F.dir[wr][t] = ndir; A.F.k[wr][t] = k_done + (last ? 0 : 1); A.F.cost[wr][t] = cost_n;
+        A.F.stop[wr][t] = last ? 1 : 0;
+        A.S.nsweeps[t] = k_done + (last ? 0 : 1);
+        if (move) {
+            A.S.last_delta[t] = md;
+            if (t == 0 && k_done <= A.hist.cap) { A.hist.a[k_done - 1] = ma; A.hist.b[k_done - 1] = mb; A.hist.d[k_done - 1] = md; }
+        }
+    }
+    if (last) return;   // sweep cap reached: the move is applied and recorded, no further sweep (the next launch raises `done`)
+    __syncthreads(); // nodes[] visible
+    STAMP(1);
+
+    // every row of the run in flight at once
+    VT R[PMAX + 1][NCH];
+#pragma unroll
+    for (int r = 0; r <= PMAX; r++) {
+        if (r <= cnt && A.ablate != 2) {
+            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[r] * ld);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) R[r][c] = src[min(c * BT + tid, nvec - 1)];
+        }
+    }
+
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
+    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
+    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
+    constexpr bool PACKED = std::is_same<AT, int>::value;
+    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
+    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
+    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
+    bool have = false;
+
+    auto step = [&](int s) __attribute__((always_inline)) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const T *bA = rows + (size_t)s * ld;
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
+        if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
+        if (A.ablate == 1) return;
+        const AT d_a = (AT)bA[sa];            // c[a][succ a]
+        // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
+        const int lo = a + 1 == n ? 0 : a + 1;
+        const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
+            if (w0 >= n) continue;                          // pad wave
+            int t0 = w0 - lo;
+            if (t0 < 0) t0 += n;
+            const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
+            const bool inside = nowrap && t0 + 64 * V <= len;
+            if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
+            const int b0 = (c * BT + tid) * V;
+            const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
+            AT g[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
+            if constexpr (PACKED) {
+                // groups of 4 independent keys + a min tree each: short dependency chains, and the
+                // only serial dependency on best_k is one compare per chunk
+                auto keys = [&](auto check_tag) __attribute__((always_inline)) {
+                    constexpr bool CHECK = decltype(check_tag)::value;
+                    constexpr int GR = V < 4 ? V : 4;
+                    long long acc = 0x7fffffffffffffffll;
+#pragma unroll
+                    for (int v0 = 0; v0 < V; v0 += GR) {
+                        long long key[GR];
+#pragma unroll
+                        for (int u = 0; u < GR; u++) {
+                            const int v = v0 + u;
+                            const int b = b0 + v;
+                            bool ok = (unsigned)(s - jb[c][v]) > 2u;   // not b in {pred a, a, succ a}
+                            if constexpr (CHECK) {
+                                int tt = b - lo;
+                                tt += (tt >> 31) & n;
+                                ok &= (unsigned)tt < (unsigned)len;
+                            }
+                            int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
+                            delta = ok ? delta : BIG;
+                            const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                            key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
+                        }
+#pragma unroll
+                        for (int w = GR / 2; w >= 1; w /= 2)
+#pragma unroll
+                            for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
+                        acc = key[0] < acc ? key[0] : acc;
+                    }
+                    best_k = acc < best_k ? acc : best_k;
+                };
+                if (inside) keys(std::false_type{}); else keys(std::true_type{});
+            } else {
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    const int b = b0 + v;
+                    bool ok = (unsigned)(s - jb[c][v]) > 2u;       // not b in {pred a, a, succ a}
+                    if (!inside) {
+                        int tt = b - lo;
+                        tt += (tt >> 31) & n;
+                        ok &= (unsigned)tt < (unsigned)len;
+                    }
+                    const AT made = (AT)vget(xa, v) + g[v];
+                    const AT kept = d_a + dnv[c][v];
+                    const AT delta = made - kept;               // refinment.c:58-60
+                    const bool lt = ok & (delta < best_d);
+                    bool eq = ok & (delta == best_d);
+                    if constexpr (!TABU) eq &= delta < (AT)0;
+                    if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                        if (eq) {
+                            const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                            const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                           : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                            if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                        }
+                    }
+                    best_d = lt ? delta : best_d;
+                    best_a = lt ? a : best_a;
+                    best_b = lt ? b : best_b;
+                    have = have | lt;
+                }
+            }
+        }
+    };
+
+    // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
+    // are in LDS runs while the later rows are still in flight (3 barriers in all for P = 8).
+    constexpr int RPC = 3;
+    {
+        int s = 0;
+#pragma unroll
+        for (int r0 = 0; r0 <= PMAX; r0 += RPC) {
+#pragma unroll
+            for (int r = r0; r < r0 + RPC && r <= PMAX; r++) {
+                if (r <= cnt && A.ablate != 2) {
+                    VT *dst = reinterpret_cast<VT *>(rows + (size_t)r * ld);
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = R[r][c];
+                }
+            }
+            __syncthreads();
+            if (r0 == 0) STAMP(2);
+            const int s_end = min(cnt, r0 + RPC - 1);   // steps s with row s+1 <= r0+RPC-1
+            for (; s < s_end; s++) step(s);
+        }
+    }
+
+    STAMP(3);
+    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
+    if constexpr (PACKED) {
+        best_d = (AT)(int)(best_k >> 32);
+        best_a = (int)(((unsigned)best_k) >> 16);
+        best_b = (int)(((unsigned)best_k) & 0xffffu);
+        have = TABU ? best_d < BIG / 2 : best_d < 0;
+    }
+    double d = (double)best_d;
+    u64 key;
+    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.F.partial[wr][(size_t)t * A.S.pstride + blockIdx.x] = o;
+    }
+    STAMP(4);
+#undef STAMP
+}
+
 // ---------------------------------------------------------------------------
 // Matrix-free ("on the fly") sweep: for instances whose matrix row does not fit LDS or whose
 // n x n matrix should not be built at all (BASELINE config 5: pla85900, 59 GB of doubles in the
@@ -1408,6 +1795,10 @@ struct tspgpu_ctx {
     unsigned long long *d_stamps = nullptr;
     size_t plan_lds = 0;
 
+    Fused F{};                 // fused path state (allocated on first use, capacity fcap)
+    int fcap = 0;
+    int opt_fused = 1;         // 1 = one launch per sweep where applicable
+
     std::vector<GraphEntry> graphs;
 
     // timing
@@ -1451,6 +1842,16 @@ static void free_tours(tspgpu_ctx *ctx)
     for (void *p : ptrs) if (p) hipFree(p);
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->h_costs) hipHostFree(ctx->h_costs);
+    {
+        Fused &F = ctx->F;
+        for (int p = 0; p < 2; p++) {
+            void *fp[] = {F.ord[p], F.pos[p], F.nl[p], F.nr[p], F.dl[p], F.dr[p], F.dir[p], F.k[p], F.stop[p], F.cost[p], F.partial[p]};
+            for (void *q : fp) if (q) hipFree(q);
+        }
+        if (F.cur) hipFree(F.cur);
+        memset(&F, 0, sizeof F);
+        ctx->fcap = 0;
+    }
     memset(&S, 0, sizeof S);
     ctx->d_starts = ctx->d_caps = ctx->d_tabu_list = ctx->d_best_succ = nullptr;
     ctx->d_tabu = nullptr; ctx->h_status = nullptr; ctx->h_costs = nullptr; ctx->tcap = 0;
@@ -1560,6 +1961,14 @@ static const void *res_kernel(int elem, int nch, bool tabu)
     const void *fn = nullptr;
     ELEM_SWITCH(elem, T, fn = nch == 1 ? (tabu ? res_fn<T, 1, true>() : res_fn<T, 1, false>())
                                        : (tabu ? res_fn<T, 2, true>() : res_fn<T, 2, false>()));
+    return fn;
+}
+
+template <typename T, int NCH> static const void *fused_fn() { return (const void *)k_sweep_fused<T, NCH, 8>; }
+static const void *fused_kernel(int elem, int nch)
+{
+    const void *fn = nullptr;
+    ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1>() : fused_fn<T, 2>());
     return fn;
 }
 
@@ -1680,6 +2089,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     if (n > 64 * 1024) return fail(ctx, E_EXHAUSTED, "n=%d exceeds the matrix-mode limit", n);
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
     // raise the dynamic-LDS cap of the kernels we are going to launch
+    if (kernel == 3) {
+        const void *ff = fused_kernel(ctx->elem, nch);
+        HIP_TRY(hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
+    }
     for (int tabu = 0; tabu < 2; tabu++) {
         const void *fn = kernel == 3 ? res_kernel(ctx->elem, nch, tabu)
                        : kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
@@ -1740,6 +2153,118 @@ static double now_s()
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+static int ensure_fused(tspgpu_ctx *ctx)
+{
+    if (ctx->fcap >= ctx->tcap) return E_OK;
+    Fused &F = ctx->F;
+    const size_t T = (size_t)ctx->tcap, N = (size_t)ctx->n, slack = 64;
+    for (int p = 0; p < 2; p++) {
+        HIP_TRY(hipMalloc(&F.ord[p], (T * N + slack) * 4));
+        HIP_TRY(hipMalloc(&F.pos[p], (T * N + slack) * 4));
+        HIP_TRY(hipMalloc(&F.nl[p], (T * N + slack) * 4));
+        HIP_TRY(hipMalloc(&F.nr[p], (T * N + slack) * 4));
+        HIP_TRY(hipMalloc(&F.dl[p], (T * N + slack) * 8));
+        HIP_TRY(hipMalloc(&F.dr[p], (T * N + slack) * 8));
+        HIP_TRY(hipMalloc(&F.dir[p], T * 4));
+        HIP_TRY(hipMalloc(&F.k[p], T * 4));
+        HIP_TRY(hipMalloc(&F.stop[p], T * 4));
+        HIP_TRY(hipMalloc(&F.cost[p], T * 8));
+        HIP_TRY(hipMalloc(&F.partial[p], T * (size_t)ctx->S.pstride * sizeof(Partial)));
+        HIP_TRY(hipMemsetAsync(F.pos[p], 0, (T * N + slack) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(F.nl[p], 0, (T * N + slack) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(F.nr[p], 0, (T * N + slack) * 4, ctx->stream));
+        HIP_TRY(hipMemsetAsync(F.dl[p], 0, (T * N + slack) * 8, ctx->stream));
+        HIP_TRY(hipMemsetAsync(F.dr[p], 0, (T * N + slack) * 8, ctx->stream));
+    }
+    HIP_TRY(hipMalloc(&F.cur, T * 4));
+    ctx->fcap = ctx->tcap;
+    return E_OK;
+}
+
+static int launch_fused(tspgpu_ctx *ctx, int slot0, int ntours, int parity)
+{
+    SweepArgs A;
+    memset(&A, 0, sizeof A);
+    A.S = ctx->S;
+    A.mat = ctx->d_mat;
+    A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.P = ctx->plan_P;
+    A.symmetric = 1;
+    A.ablate = ctx->opt_ablate;
+    A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
+    A.pts = ctx->d_pts; A.spts = nullptr; A.kind = ctx->kind;
+    A.F = ctx->F; A.parity = parity; A.hist = ctx->hist;
+    const void *fn = fused_kernel(ctx->elem, ctx->plan_NCH);
+    void *args[] = {&A};
+    HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
+    return E_OK;
+}
+
+// One launch per sweep (k_sweep_fused): begin, batches of an even number of launches with
+// alternating parity (replayed as a hipGraph), end.
+static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s, bool *deadline_hit)
+{
+    int rc = ensure_fused(ctx);
+    if (rc) return rc;
+    const int n = ctx->n;
+    const bool f64 = ctx->elem == TSPGPU_ELEM_F64;
+    const dim3 grid1((n + 255) / 256, ntours);
+    if (f64) hipLaunchKernelGGL((k_fused_begin<double>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
+    else hipLaunchKernelGGL((k_fused_begin<int>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
+    HIP_TRY(hipGetLastError());
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    const int K = std::max(2, ctx->opt_batch & ~1);
+    long issued = 0;
+    for (;;) {
+        const bool use_graph = ctx->opt_graph && !ctx->opt_timing;
+        if (use_graph) {
+            hipGraphExec_t exec = nullptr;
+            for (auto &g : ctx->graphs)
+                if (g.slot0 == slot0 && g.ntours == ntours && g.tabu == 2 && g.K == K) exec = g.exec;
+            if (!exec) {
+                hipGraph_t graph;
+                HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+                for (int i = 0; i < K && !rc; i++) rc = launch_fused(ctx, slot0, ntours, i & 1);
+                hipError_t ce = hipStreamEndCapture(ctx->stream, &graph);
+                if (rc) return rc;
+                if (ce != hipSuccess) return fail(ctx, E_INTERNAL, "graph capture failed: %s", hipGetErrorString(ce));
+                HIP_TRY(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                hipGraphDestroy(graph);
+                ctx->graphs.push_back({slot0, ntours, 2, K, exec});
+            }
+            HIP_TRY(hipGraphLaunch(exec, ctx->stream));
+        } else {
+            while (ctx->opt_timing && (int)ctx->ev.size() < 2 * K) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            for (int i = 0; i < K; i++) {
+                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i], ctx->stream));
+                if ((rc = launch_fused(ctx, slot0, ntours, i & 1))) return rc;
+                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i + 1], ctx->stream));
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->opt_timing)
+            HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->opt_timing) {
+            int live = 0; // launches 0 .. nsweeps-1 swept (launch nsweeps only found the tour finished)
+            for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
+            for (int i = 0; i < K && issued + i < live; i++) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
+                ctx->sweep_ms_total += ms; ctx->sweep_launches++;
+            }
+        }
+        issued += K;
+        bool all = true;
+        for (int i = 0; i < ntours; i++) if (!ctx->h_status[i]) { all = false; break; }
+        if (all) break;
+        if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
+    }
+    if (f64) hipLaunchKernelGGL((k_fused_end<double>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    else hipLaunchKernelGGL((k_fused_end<int>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    HIP_TRY(hipGetLastError());
+    return E_OK;
+}
+
 // Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
 // done, `max_iters` pairs were issued (tabu), or the deadline passed.
 static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s,
@@ -1751,6 +2276,12 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
         if (rc) return rc;
         drop_graphs(ctx);
     }
+    // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
+    // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
+    // tour at once and the leaner sweep wins (measured 7.0e11 vs 5.0e11 evals/s at 64 tours).
+    if (!tabu && ctx->plan_kernel == 3 && ctx->symmetric && !ctx->opt_stamps &&
+        (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
+        return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     const int K = std::max(1, ctx->opt_batch);
     long issued = 0;
@@ -1982,6 +2513,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
         if (value) HIP_TRY(hipMemset(ctx->d_stamps, 0, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
         break;
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
+    case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
@@ -2003,6 +2535,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 8: return ctx->cus;
     case 9: return ctx->plan_D;
     case 10: return ctx->otf ? 1 : 0;
+    case 11: return (ctx->plan_kernel == 3 && ctx->symmetric && ctx->opt_fused) ? 1 : 0;
     }
     return -1;
 }
