@@ -182,8 +182,9 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         tmax, tot_sweeps = float(t.item()), int(s.item())
 
-    # ---- roofline of the dominant kernel: same search once more, every sweep launch bracketed
-    # by HIP events on the engine's stream (eager launches; the timed region above replays graphs)
+    # ---- roofline of the dominant kernel: the same search once more with HIP events on the engine's
+    # stream: around every batch of back-to-back launches on the one-launch-per-sweep path (batch
+    # time / launches), around every sweep launch otherwise
     roof = None
     if rank == 0:
         eng.set_option(T.OPT_TIMING, 1)
@@ -199,10 +200,11 @@ def main():
         back2back_ms = eng.time_sweep(1, 50)                         # 50 launches, no apply in between
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(f"n{n}_{NAMES[info['elem']]}"),
-                "kernel": {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res"}[info["kernel"]],
+                "traffic": load_traffic(f"n{n}_{NAMES[info['elem']]}" + ("_fused" if info.get("fused") else "")),
+                "kernel": "k_sweep_fused (sweep + apply of the previous move, one launch per sweep)" if info.get("fused") else
+                          {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res", 4: "k_sweep_otf"}[info["kernel"]],
                 "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
-                "kernel_ms_back_to_back": back2back_ms,
+                "kernel_ms_back_to_back": back2back_ms,   # the sweep part alone (no move applied between launches)
                 "algorithmic_bytes_per_launch": evals * bytes_per_eval,
                 "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals,
                 "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}

@@ -2215,8 +2215,14 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
     const int K = std::max(2, ctx->opt_batch & ~1);
     long issued = 0;
     for (;;) {
-        const bool use_graph = ctx->opt_graph && !ctx->opt_timing;
-        if (use_graph) {
+        // timing mode: one event pair around the whole batch (the launches of a batch run back to
+        // back, so batch time / K is the mean launch duration); only batches in which every launch
+        // swept are counted
+        if (ctx->opt_timing) {
+            while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        }
+        if (ctx->opt_graph) {
             hipGraphExec_t exec = nullptr;
             for (auto &g : ctx->graphs)
                 if (g.slot0 == slot0 && g.ntours == ntours && g.tabu == 2 && g.K == K) exec = g.exec;
@@ -2233,13 +2239,10 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
             }
             HIP_TRY(hipGraphLaunch(exec, ctx->stream));
         } else {
-            while (ctx->opt_timing && (int)ctx->ev.size() < 2 * K) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
-            for (int i = 0; i < K; i++) {
-                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i], ctx->stream));
+            for (int i = 0; i < K; i++)
                 if ((rc = launch_fused(ctx, slot0, ntours, i & 1))) return rc;
-                if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[2 * i + 1], ctx->stream));
-            }
         }
+        if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->opt_timing)
             HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -2247,10 +2250,10 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
         if (ctx->opt_timing) {
             int live = 0; // launches 0 .. nsweeps-1 swept (launch nsweeps only found the tour finished)
             for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
-            for (int i = 0; i < K && issued + i < live; i++) {
+            if (issued + K <= live) {
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[2 * i], ctx->ev[2 * i + 1]));
-                ctx->sweep_ms_total += ms; ctx->sweep_launches++;
+                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+                ctx->sweep_ms_total += ms; ctx->sweep_launches += K;
             }
         }
         issued += K;

@@ -145,7 +145,7 @@ ERROR_CODE tsp_compute_costs(void)
      * past 46 340 and needs 59 GB for pla85900) or on request: no n x n array anywhere, the
      * device recomputes weights from the coordinates and tsp_inst.costs stays NULL. */
     const char *mf = getenv("TSP_MATRIX_FREE");
-    tsp_matrix_free = (mf && atoi(mf) != 0) || n > 32768;
+    tsp_matrix_free = mf ? atoi(mf) != 0 : n > 32768;   /* an explicit 0 keeps the matrix at any size */
     if (tsp_matrix_free) {
         tspgpu_set_option(g, TSPGPU_OPT_MATRIX_FREE, 1);
         rc = tspgpu_build_costs(g, NULL);
