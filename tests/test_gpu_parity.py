@@ -32,8 +32,8 @@ def fx(O, v):
 
 
 # (matrix storage, sweep kernel): storage 1 f64, 2 int32, 3 uint16; kernel 1 simple, 2 pipelined,
-# 3 resident (the pipelined kernel has no uint16 variant)
-COMBOS = [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (3, 1), (3, 3)]
+# 3 resident
+COMBOS = [(1, 1), (1, 2), (1, 3), (2, 1), (2, 2), (2, 3), (3, 1), (3, 2), (3, 3)]
 
 
 def setup(eng, T, O, instances, name, elem, kernel=0):

@@ -8,12 +8,16 @@ import travellingsalesmanoptimization_amd as T
 from bench import reference_points
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 xy = reference_points(n, 123)
+only = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+ab = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 for elem, ename in [(T.ELEM_U16, "u16"), (T.ELEM_I32, "i32"), (T.ELEM_F64, "f64")]:
+    if only and ename not in only: continue
     eng = T.Engine(0)
     eng.set_option(T.OPT_ELEM, elem)
     eng.set_points(xy); eng.build_costs(); eng.tour_nn(0, 0)
     for block, wgs, depth in [(0, 0, 0)]:
         eng.set_option(T.OPT_BLOCK, block); eng.set_option(T.OPT_WGS_PER_TOUR, wgs); eng.set_option(T.OPT_DEPTH, depth)
+        eng.set_option(T.OPT_FUSED, 0); eng.set_option(99, ab)
         eng.time_sweep(0, 3)
         eng.set_option(98, 1)
         ms = eng.time_sweep(0, 1)      # warm launch + 1 timed launch: stamps are from the last one
@@ -37,10 +41,15 @@ for elem, ename in [(T.ELEM_U16, "u16"), (T.ELEM_I32, "i32"), (T.ELEM_F64, "f64"
         else:
             line = []
             prev = st[wg, 2]
-            for s in range(24):
+            for s in range(12):
                 c, l = st[wg, 8 + 2 * s], st[wg, 9 + 2 * s]
                 if c == 0: break
                 line.append(f"{(c - prev)/100.0:.2f}+{(l - c)/100.0:.2f}")
                 prev = l
             print(f"   slowest wg {wg}: per step compute+wait(us): " + " ".join(line))
+            if st[wg, 32] > 0:
+                w0 = st[wg, 32:48].min()
+                nw = (i["block"] + 63) // 64
+                print("   step 10 per wave, enter->evaluated (us after the first wave entered): " +
+                      " ".join(f"{(st[wg, 32 + w] - w0)/100.0:.2f}->{(st[wg, 48 + w] - w0)/100.0:.2f}" for w in range(nw)))
     eng.close()

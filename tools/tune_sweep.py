@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Sweep-kernel tuning table on the GPU box: mean back-to-back duration of the sweep kernel
-for (elem, block, wgs_per_tour) grids.  usage: python tools/tune_sweep.py [n] [seed]"""
+for (elem, block, wgs_per_tour) grids.  usage: python tools/tune_sweep.py [n] [seed] [u16,i32,f64]"""
 import os, sys, itertools
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,7 +13,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 123
 xy = reference_points(n, seed)
 ev = T.evals_per_sweep(n)
-for elem, ename, bpe in [(T.ELEM_I32, "i32", 8), (T.ELEM_F64, "f64", 16)]:
+only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+for elem, ename, bpe in [(T.ELEM_U16, "u16", 4), (T.ELEM_I32, "i32", 8), (T.ELEM_F64, "f64", 16)]:
+    if only and ename not in only: continue
     eng = T.Engine(0)
     eng.set_option(T.OPT_ELEM, elem)
     eng.set_points(xy); eng.build_costs()

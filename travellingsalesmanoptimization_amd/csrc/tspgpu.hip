@@ -66,6 +66,8 @@ struct Partial {
 // as an exact int32 copy (every integer-valued matrix: EUC_2D, ATT, CEIL_2D)
 // ---------------------------------------------------------------------------
 typedef unsigned short u16;
+typedef __attribute__((address_space(3))) unsigned char lds_u8;
+typedef __attribute__((address_space(3))) unsigned short lds_u16;
 typedef double v2f64 __attribute__((ext_vector_type(2)));
 typedef int v4i32 __attribute__((ext_vector_type(4)));
 typedef u16 v8u16 __attribute__((ext_vector_type(8)));
@@ -560,9 +562,9 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
 }
 
 // ---------------------------------------------------------------------------
-// K2/K3 "pipelined" sweep: the speed-of-light form for rows that fit LDS three
-// times.  Workgroup g owns a run of cnt consecutive tour edges and needs the
-// cnt+1 matrix rows of the nodes on that run, each exactly once:
+// K2 "pipelined" sweep: the streaming form for rows that fit LDS three times (any cell type;
+// uint16 rows up to n ~ 27 000).  Workgroup g owns a run of cnt consecutive tour edges and
+// needs the cnt+1 matrix rows of the nodes on that run, each exactly once:
 //     row r   (node a)  : c[a][b], read conflict-free from LDS at the thread's
 //                         OWN b's (b fixed per thread for the whole kernel, so
 //                         succ b and c[b][succ b] live in registers)
@@ -573,12 +575,15 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
 // so every matrix byte is fetched once per sweep (+1 row per run) with 16-byte
 // coalesced loads, up to D rows per workgroup are in flight at any time, and
 // one barrier separates steps.  Both orientations of a pair meet in LDS;
-// pair_owned() keeps one.
+// pair_owned() keeps one.  The three pairs the reference skips (refinment.c:55: b == a,
+// b == succ a, succ b == a, i.e. b in {a_s, a_s+1, a_s-1}) are masked per WAVE: a wave whose
+// b range holds none of the three nodes (a scalar test) runs the unmasked variant.
 // ---------------------------------------------------------------------------
 template <typename T, int NCH, int D, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 {
     typedef typename Elem<T>::vec VT;
+    typedef typename Elem<T>::acc AT;
     constexpr int V = Elem<T>::V;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = A.n, ld = A.ld;
@@ -587,17 +592,14 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nvec = ld / V; // 16-byte vectors per row
 
-    // LDS: 3 row buffers | nodes[-1 .. P] | dcell[2] | reduction scratch
+    // LDS: 3 row buffers | nodes[-1 .. P] | 16 spare bytes | reduction scratch
     T *buf = reinterpret_cast<T *>(smem);
     int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)) + 1; // nodes[-1] = node before the run
     const size_t nodes_bytes = (size_t)((A.P + 2 + 3) & ~3) * 4;
-    T *dcell = reinterpret_cast<T *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes);
     Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes + 16);
 
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
-    const int *pos = A.S.pos + (size_t)t * n;
-    const T *dp = dpos_of<T>(A.S, t, n);
     const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
@@ -615,19 +617,24 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     // per-thread state of the owned b's: LDS byte offset of succ b, and c[b][succ b].
     // A b that can never be part of a move from this thread (pad lane, tabu) gets the poison
     // value instead, which drives every delta it takes part in far above any real one.
-    // Load order: pos[b] and the run's nodes first (one round trip), then the matrix rows are
-    // issued, and only then the loads that depend on pos[b]: two dependent trips, not three.
-    const T BIG = Elem<T>::big();
+    // uint16 cells: the LDS byte offset of succ b (< 2 ld <= 65534) and c[b][succ b] share ONE
+    // register per b, low / high half (half the registers; the halves are SDWA operands, so
+    // unpacking is free).  No poison value exists then: tabu b's are a bit mask and pad lanes
+    // only ever meet the masked variant.
+    constexpr bool PKS = sizeof(T) == 2;
+    const AT BIG = Elem<T>::big();
+    constexpr int MASKED32 = 1 << 27;   // masked pair on the 32-bit key path: (x << 3) must not overflow
     int sboff[NCH][V];
-    T dnv[NCH][V];
+    AT dnv[PKS ? 1 : NCH][PKS ? 1 : V];
+    unsigned skm = 0;
     {
         const int *succ = A.S.succ + (size_t)t * n;
-        const T *dnb = dnb_of<T>(A.S, t, n);
+        const AT *dnb = dnb_of<AT>(A.S, t, n);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const int b0 = min((c * BT + tid) * V, ld - V);
             int sv[V];
-            T dv[V];
+            AT dv[V];
             load_run<V>(succ + b0, sv);
             load_run<V>(dnb + b0, dv);
 #pragma unroll
@@ -637,8 +644,13 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
                 bool sk = b >= n;
                 if constexpr (TABU)
                     if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-                sboff[c][v] = sb * (int)sizeof(T);
-                dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+                if constexpr (PKS) {
+                    sboff[c][v] = (sb * (int)sizeof(T)) | ((int)dv[v] << 16);
+                    if (TABU && sk) skm |= 1u << (c * V + v);
+                } else {
+                    sboff[c][v] = sb * (int)sizeof(T);
+                    dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+                }
             }
         }
     }
@@ -664,107 +676,187 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     // row r travels through register set r % D
 #pragma unroll
     for (int r = 0; r < D; r++) issue(R[r], r);
-    // prep(s): make the landed row of a_s ready to be the "row a" buffer of step s.  The
-    // three pairs the reference skips (refinment.c:55: b == a, b == succ a, succ b == a,
-    // i.e. b in {a_s, a_s+1, a_s-1}) are removed by poisoning their c[a][b] cells, after
-    // c[a][succ a] has been saved for the step.  One lane; runs while the row is still
-    // only a gather target (step s-1): the cells it touches are read there only by pairs
-    // that are poisoned themselves.
-    auto prep = [&](int s) __attribute__((always_inline)) {
-        if (tid == 0 && s < cnt) {
-            T *row = buf + (size_t)(s % 3) * ld;
-            const int am = nodes[s - 1], a0 = nodes[s], ap = nodes[s + 1];
-            dcell[s & 1] = row[ap];
-            row[am] = BIG; row[a0] = BIG; row[ap] = BIG;
-        }
-    };
-
     land(R[0], 0);
     land(R[1 % D], 1);
     issue(R[0], D);
     issue(R[1 % D], D + 1);
     __syncthreads();
-    prep(0);
-    __syncthreads();
     STAMP(2);
 
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    T best_d = TABU ? Elem<T>::lim() : (T)0;
+    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
+    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
+    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
+    constexpr bool PACKED = std::is_same<AT, int>::value;
+    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
+    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
     int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
     bool have = false;
 
-    auto eval = [&](auto check_tag, int a, const VT &xa, const T(&g)[V], const T(&dn)[V], T d_a, int b0, int lo, int len)
-        __attribute__((always_inline)) {
-        constexpr bool CHECK = decltype(check_tag)::value;
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-            const int b = b0 + v;
-            T delta;
-            if constexpr (sizeof(T) == 4) delta = vget(xa, v) + g[v] - (d_a + dn[v]);
-            else { const T made = vget(xa, v) + g[v]; const T kept = d_a + dn[v]; delta = made - kept; } // refinment.c:58-60
-            bool ok = true;
-            if constexpr (CHECK) {
-                int tt = b - lo;
-                tt += (tt >> 31) & n;
-                ok = (unsigned)tt < (unsigned)len;
-            }
-            const bool lt = ok & (delta < best_d);
-            bool eq = ok & (delta == best_d);
-            if constexpr (!TABU) eq &= delta < (T)0;
-            if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
-                if (eq) {
-                    const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
-                    const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
-                                                   : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
-                    if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
-                }
-            }
-            best_d = lt ? delta : best_d;
-            best_a = lt ? a : best_a;
-            best_b = lt ? b : best_b;
-            have = have | lt;
-        }
-    };
-
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;   // LDS byte address of the row buffers
     auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
         const T *bA = buf + (size_t)(s % 3) * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
+        if (stamp && s == 10 && (tid & 63) == 0) stamp[32 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 entered
         bool live = A.ablate != 1;
-        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, nodes[s + 1], iter, tenure));
+        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
         if (live) {
-            const T d_a = dcell[s & 1]; // c[a][succ a]
-            // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
-            // (pair_owned(): half way round the index circle; ties at n/2 go to the lower a)
+            const AT d_a = (AT)bA[sa]; // c[a][succ a]
+            // Which orientation of a pair evaluates it.  Symmetric matrix, plain 2-opt: by BLOCKS of
+            // 64 V node indices (= what one wave holds in one chunk).  Pair {a, b} in different
+            // blocks belongs to the orientation whose b block lies less than half way round the
+            // block circle ahead of a's block (exactly half way: to the lower block); inside a's
+            // own block to b > a.  So a wave is either wholly in, wholly out, or the one wave
+            // holding a's block -- no wave straddles a range boundary, and the b's of the two
+            // neighbours of a need no mask at all: their delta is exactly 0 (c[a][pa] + c[sa][a] -
+            // (c[a][sa] + c[pa][a]), IEEE addition commutes), never an improvement.
+            // Otherwise (caller matrix not symmetric: b > a; tabu: every admissible pair counts,
+            // also non-improving ones): the cyclic index range [lo, lo+len-1], masked per lane
+            // wherever a wave straddles its ends or holds one of the three nodes around a.
+            const bool blocks = A.symmetric && !TABU;
+            const int NB = (n + 64 * V - 1) / (64 * V);
+            const int blka = a / (64 * V);
             const int lo = a + 1 == n ? 0 : a + 1;
             const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
 #pragma unroll
             for (int c = 0; c < NCH; c++) {
                 const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
                 if (w0 >= n) continue;                          // pad wave
-                int t0 = w0 - lo;
-                if (t0 < 0) t0 += n;
-                const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
-                const bool inside = nowrap && t0 + 64 * V <= len;
-                const bool outside = nowrap && t0 >= len;
-                if (outside) continue;                          // wave-uniform
+                bool clean, self = false;
+                if (blocks) {
+                    const int blkb = w0 / (64 * V);
+                    int d = blkb - blka;
+                    if (d < 0) d += NB;
+                    self = d == 0;
+                    if (!self && !(2 * d < NB || (2 * d == NB && blka < blkb))) continue;   // the other orientation's
+                    clean = !self && (!PKS || w0 + 64 * V <= n);   // packed uint16 state has no poison for pad lanes
+                } else {
+                    int t0 = w0 - lo;
+                    if (t0 < 0) t0 += n;
+                    const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
+                    if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
+                    // unmasked variant: wave entirely inside the owned range and none of the three
+                    // nodes around a among its b's
+                    clean = nowrap && t0 + 64 * V <= len && (unsigned)(am - w0) >= (unsigned)(64 * V) &&
+                            (unsigned)(a - w0) >= (unsigned)(64 * V) && (unsigned)(sa - w0) >= (unsigned)(64 * V);
+                }
                 const int b0 = (c * BT + tid) * V;
                 // all LDS reads of the chunk first (lanes past the row read its last vector;
                 // their dn is poisoned), then the arithmetic
                 const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
-                T g[V];
+                auto valid = [&](int b) __attribute__((always_inline)) {
+                    asm volatile("" : "+v"(b));     // b < n is step-invariant: hoisted, it costs an SGPR pair per b
+                    if (blocks) return ((b > a) | !self) & (b < n);
+                    int tt = b - lo;
+                    tt += (tt >> 31) & n;
+                    return ((unsigned)tt < (unsigned)len) & (b != am) & (b != a) & (b != sa) & (b < n);
+                };
+                if constexpr (PKS) {
+                    // uint16 cells.  Per pair: one SDWA add forms the gather address from the low
+                    // half of the packed register, one add and one SDWA subtract give
+                    // delta + c[a][sa] = c[a][b] + c[sa][sb] - c[b][sb] (19 bits), and the slot number v
+                    // goes into the three low bits: for a fixed a the labels (min(a,b), max(a,b)) of a
+                    // thread's eight consecutive b's ascend with v, so ONE 32-bit min per pair keeps
+                    // the reference's tie order.  c[a][sa] (uniform) comes off after the min; the
+                    // 64-bit key (delta, labels) is built once per chunk for the winner only.
+                    const unsigned rowS = lds0 + (unsigned)(((s + 1) % 3) * ld) * 2u;
+                    int g[V];
 #pragma unroll
-                for (int v = 0; v < V; v++) g[v] = *reinterpret_cast<const T *>(bS + sboff[c][v]);
-                if (inside) eval(std::false_type{}, a, xa, g, dnv[c], d_a, b0, lo, len);
-                else eval(std::true_type{}, a, xa, g, dnv[c], d_a, b0, lo, len);
+                    for (int v = 0; v < V; v++) {
+                        unsigned addr;
+                        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                            : "=v"(addr) : "v"(rowS), "v"(sboff[c][v]));
+                        g[v] = (int)*(const lds_u16 *)(uintptr_t)addr;
+                    }
+                    auto k32 = [&](auto check_tag) __attribute__((always_inline)) {
+                        constexpr bool CHECK = decltype(check_tag)::value;
+                        int m = 0x7fffffff;
+#pragma unroll
+                        for (int v = 0; v < V; v++) {
+                            int dl;
+                            const int made = (int)vget(xa, v) + g[v];
+                            asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                                : "=v"(dl) : "v"(made), "v"(sboff[c][v]));
+                            if constexpr (CHECK) dl = valid(b0 + v) ? dl : MASKED32;
+                            if constexpr (TABU) dl = ((skm >> (c * V + v)) & 1u) ? MASKED32 : dl;
+                            m = min(m, (dl << 3) | v);
+                        }
+                        const int b = b0 + (m & 7);
+                        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                        const long long key = (long long)(((u64)(unsigned)((m >> 3) - d_a) << 32) | lohi);
+                        best_k = key < best_k ? key : best_k;
+                    };
+                    if (clean) k32(std::false_type{}); else k32(std::true_type{});
+                } else if constexpr (PACKED) {
+                    AT g[V];
+#pragma unroll
+                    for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
+                    // groups of 4 independent keys + a min tree each: short dependency chains, and the
+                    // only serial dependency on best_k is one compare per chunk
+                    auto keys = [&](auto check_tag) __attribute__((always_inline)) {
+                        constexpr bool CHECK = decltype(check_tag)::value;
+                        constexpr int GR = V < 4 ? V : 4;
+                        long long acc = 0x7fffffffffffffffll;
+#pragma unroll
+                        for (int v0 = 0; v0 < V; v0 += GR) {
+                            long long key[GR];
+#pragma unroll
+                            for (int u = 0; u < GR; u++) {
+                                const int v = v0 + u;
+                                const int b = b0 + v;
+                                int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
+                                if constexpr (CHECK) delta = valid(b) ? delta : BIG;
+                                const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                                key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
+                            }
+#pragma unroll
+                            for (int w = GR / 2; w >= 1; w /= 2)
+#pragma unroll
+                                for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
+                            acc = key[0] < acc ? key[0] : acc;
+                        }
+                        best_k = acc < best_k ? acc : best_k;
+                    };
+                    if (clean) keys(std::false_type{}); else keys(std::true_type{});
+                } else {
+                    AT g[V];
+#pragma unroll
+                    for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
+#pragma unroll
+                    for (int v = 0; v < V; v++) {
+                        const int b = b0 + v;
+                        const bool ok = clean || valid(b);
+                        const AT made = (AT)vget(xa, v) + g[v];
+                        const AT kept = d_a + dnv[c][v];
+                        const AT delta = made - kept;               // refinment.c:58-60
+                        const bool lt = ok & (delta < best_d);
+                        bool eq = ok & (delta == best_d);
+                        if constexpr (!TABU) eq &= delta < (AT)0;
+                        if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                            if (eq) {
+                                const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                                const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
+                                                               : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+                                if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
+                            }
+                        }
+                        best_d = lt ? delta : best_d;
+                        best_a = lt ? a : best_a;
+                        best_b = lt ? b : best_b;
+                        have = have | lt;
+                    }
+                }
             }
         }
-        if (stamp && tid == 0 && s < 24) stamp[8 + 2 * s] = wall_clock64();      // compute done
-        prep(s + 1);
+        if (stamp && tid == 0 && s < 12) stamp[8 + 2 * s] = wall_clock64();      // compute done
+        if (stamp && s == 10 && (tid & 63) == 0) stamp[48 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 evaluated
         if (s + 2 <= cnt) land(Rs, (s + 2) % 3);
         issue(Rs, s + 2 + D);
         __syncthreads();
-        if (stamp && tid == 0 && s < 24) stamp[9 + 2 * s] = wall_clock64();      // row landed, barrier passed
+        if (stamp && tid == 0 && s < 12) stamp[9 + 2 * s] = wall_clock64();      // row landed, barrier passed
     };
 
     {
@@ -780,15 +872,22 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 
     STAMP(3);
     // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
+    if constexpr (PACKED) {
+        best_d = (AT)(int)(best_k >> 32);
+        best_a = (int)(((unsigned)best_k) >> 16);
+        best_b = (int)(((unsigned)best_k) & 0xffffu);
+        have = TABU ? best_d < MASKED32 / 2 : best_d < 0;
+    }
     double d = (double)best_d;
     u64 key;
-    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    if (!have || best_d >= (PKS ? (AT)(MASKED32 / 2) : BIG / 2)) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
     else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
         A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
     }
+#undef STAMP
 }
 
 
@@ -1121,7 +1220,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
-    STAMP(0);
+    const unsigned long long t_entry = stamp ? wall_clock64() : 0ull;   // recorded at STAMP(1): launches that leave early keep the last sweep's stamps
 
     // ---- the move found by the previous launch (every workgroup reduces the same partials)
     double md = 0.0;
@@ -1134,6 +1233,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         }
         block_argmin(md, mkey, scratch);
     }
+    const unsigned long long t_red = stamp ? wall_clock64() : 0ull;
     const bool move = k_done > 0 && md < TWO_OPT_EPS;
     if (A.F.stop[rd][t] || (k_done > 0 && !move)) {
         // either the previous launch applied the last move a sweep cap allows, or the previous
@@ -1249,6 +1349,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
     if (last) return;   // sweep cap reached: the move is applied and recorded, no further sweep (the next launch raises `done`)
     __syncthreads(); // nodes[] visible
+    if (stamp && tid == 0) { stamp[0] = t_entry; stamp[5] = t_red; }
     STAMP(1);
 
     // every row of the run in flight at once
@@ -1944,11 +2045,18 @@ static const void *pipe_kernel(int elem, int nch, int depth, bool tabu)
         case 2: return depth == 4 ? PK(double, 2, 4) : PK(double, 2, 2);
         case 4: return PK(double, 4, 2);
         }
-    } else {
+    } else if (elem == TSPGPU_ELEM_I32) {
         switch (nch) {
         case 1: return depth == 8 ? PK(int, 1, 8) : depth == 4 ? PK(int, 1, 4) : PK(int, 1, 2);
         case 2: return depth == 4 ? PK(int, 2, 4) : PK(int, 2, 2);
         case 4: return PK(int, 4, 2);
+        }
+    } else {
+        switch (nch) {
+        case 1: return depth >= 4 ? PK(u16, 1, 4) : PK(u16, 1, 2);
+        case 2: return depth >= 4 ? PK(u16, 2, 4) : PK(u16, 2, 2);
+        case 3: return PK(u16, 3, 2);
+        case 4: return PK(u16, 4, 2);
         }
     }
 #undef PK
@@ -2030,7 +2138,6 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         ctx->plan_T = ntours; ctx->plan_lds = 0;
         return E_OK;
     }
-    if (ctx->elem == TSPGPU_ELEM_U16 && kernel == 2) return fail(ctx, E_INVALID, "the pipelined sweep has no uint16 variant");
     // resident sweep: all P+1 (<= 9) rows of a run in LDS at once.  One chunk per thread for
     // uint16 (two would spill), at most two otherwise.
     const int res_bt = std::min(1024, std::max(64, (nvec + 63) & ~63));
@@ -2047,7 +2154,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         // uint16: resident whenever it fits.  int32 / f64: resident only while 9 rows leave room
         // for two workgroups per CU (small n, multi-start batches); else pipelined; else simple.
         if (res_ok && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
-        else kernel = (pipe_fits(BT, 64) && ctx->elem != TSPGPU_ELEM_U16) ? 2 : 1;
+        else kernel = pipe_fits(BT, 64) ? 2 : 1;
     }
     if (kernel == 3) {
         BT = ctx->opt_block > 0 ? BT : res_bt;
@@ -2063,7 +2170,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     if (kernel == 2) {
         nch = (nvec + BT - 1) / BT;
         while (nch > 4 && BT < 1024) { BT *= 2; nch = (nvec + BT - 1) / BT; }
-        int inst = nch <= 1 ? 1 : nch <= 2 ? 2 : 4;
+        int inst = nch <= 1 ? 1 : nch <= 2 ? 2 : (nch == 3 && ctx->elem == TSPGPU_ELEM_U16) ? 3 : 4;
         if (nch > 4 || !pipe_fits(BT, 64)) {
             if (ctx->opt_kernel == 2) return fail(ctx, E_EXHAUSTED, "pipelined sweep: 3 rows of %zu B do not fit %zu B of LDS", row, ctx->lds_max);
             kernel = 1;
@@ -2282,7 +2389,7 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
     // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
     // tour at once and the leaner sweep wins (measured 7.0e11 vs 5.0e11 evals/s at 64 tours).
-    if (!tabu && ctx->plan_kernel == 3 && ctx->symmetric && !ctx->opt_stamps &&
+    if (!tabu && ctx->plan_kernel == 3 && ctx->symmetric &&
         (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
         return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
