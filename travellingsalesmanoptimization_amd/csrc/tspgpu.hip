@@ -562,22 +562,263 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
 }
 
 // ---------------------------------------------------------------------------
+// Shared by the LDS sweeps (pipelined, resident, fused): per-thread state of the owned b's and
+// the evaluation of one step (one tour edge (a, succ a) against the thread's b's).
+//
+// State.  A thread keeps the same V = 16 / sizeof(cell) node indices b per chunk for the whole
+// kernel: the LDS byte offset of succ b and c[b][succ b] live in registers.  uint16 cells: both
+// share ONE register per b, low / high half (the halves are SDWA operands, unpacking is free).
+// No poison value exists then: tabu b's are a bit mask and pad lanes only ever meet the masked
+// variant.  Other cells: two registers; a b that can never be part of a move from this thread
+// (pad lane, tabu) gets c[b][succ b] = -BIG, which drives its deltas far above any real one.
+//
+// Which orientation of a pair evaluates it (both meet in LDS).  Symmetric matrix, plain 2-opt:
+// by BLOCKS of 64 V node indices (= what one wave holds in one chunk).  Pair {a, b} in different
+// blocks belongs to the orientation whose b block lies less than half way round the block
+// circle ahead of a's block (exactly half way: to the lower block); inside a's own block to
+// b > a.  So a wave is either wholly in, wholly out, or the one wave holding a's block -- no
+// wave straddles a range boundary, and the b's of the two neighbours of a need no mask at all:
+// their delta is exactly 0 (c[a][pa] + c[sa][a] - (c[a][sa] + c[pa][a]); IEEE addition
+// commutes), never an improvement.  Otherwise (caller matrix not symmetric: b > a; tabu: every
+// admissible pair counts, non-improving ones too): the cyclic index range [lo, lo+len-1],
+// masked per lane wherever a wave straddles its ends or holds one of the three nodes around a
+// (refinment.c:55: b == a, b == succ a, succ b == a).
+//
+// Argmin.  The reference keeps the first strictly smaller delta in (a asc, b asc) order, i.e.
+// it minimises (delta, min(a,b), max(a,b)).  Integer deltas (n < 65536): ONE signed 64-bit word,
+// delta in the high half, so "better" is a single compare and ties need no special path.
+// uint16 cells go one step further: for a fixed a the labels of a thread's consecutive b's
+// ascend with the slot number v, so per pair a 32-bit (delta << 3 | v) and ONE v_min suffice;
+// c[a][succ a] (uniform) comes off after the min and the 64-bit key is built once per chunk,
+// for the winner.  Doubles keep (delta, a, b) and a wave-uniform tie branch; operation order
+// made = c[a][b] + c[sa][sb]; kept = c[a][sa] + c[b][sb]; made - kept (refinment.c:58-60).
+// ---------------------------------------------------------------------------
+template <typename T, int NCH> struct BState {
+    typedef typename Elem<T>::acc AT;
+    static constexpr int V = Elem<T>::V;
+    static constexpr bool PKS = sizeof(T) == 2;
+    int sb[NCH][V];                               // LDS byte offset of succ b (| c[b][succ b] << 16 when packed)
+    AT dn[PKS ? 1 : NCH][PKS ? 1 : V];            // c[b][succ b]
+    unsigned skm;                                 // packed + tabu: b's that take no part
+};
+
+template <typename T, int NCH>
+__device__ __forceinline__ void bstate_set(BState<T, NCH> &B, int c, int v, int succ_b, typename Elem<T>::acc dn, bool skip, bool tabu)
+{
+    if constexpr (BState<T, NCH>::PKS) {
+        B.sb[c][v] = (succ_b * (int)sizeof(T)) | ((int)dn << 16);
+        if (tabu && skip) B.skm |= 1u << (c * BState<T, NCH>::V + v);
+    } else {
+        B.sb[c][v] = succ_b * (int)sizeof(T);
+        B.dn[c][v] = skip ? -Elem<T>::big() : dn;   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+    }
+}
+
+struct Best {
+    long long k;          // packed key (integer deltas)
+    double d;             // doubles: (d, a, b, have)
+    int a, b;
+    bool have;
+};
+
+template <bool TABU>
+__device__ __forceinline__ void best_init(Best &q)
+{
+    q.k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;   // (lim, none) / (0, no move)
+    q.d = TABU ? DBL_MAX : 0.0;
+    q.a = 0; q.b = 0; q.have = false;                                           // (0,0): "no move"; cannot win a tie
+}
+
+constexpr int MASKED32 = 1 << 27;   // masked pair on the 32-bit key path: (x << 3) must not overflow
+
+// bA: LDS row of a; bS: LDS row of succ a (ldsS: its LDS byte address).
+// BLOCKS: block ownership (symmetric matrix, plain 2-opt); else the index range (symmetric or not).
+template <typename T, int NCH, bool TABU, bool BLOCKS>
+__device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, const T *bA, const unsigned char *bS, unsigned ldsS,
+                                              int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric)
+{
+    static_assert(!(BLOCKS && TABU), "block ownership is for plain 2-opt");
+    typedef typename Elem<T>::vec VT;
+    typedef typename Elem<T>::acc AT;
+    constexpr int V = Elem<T>::V;
+    constexpr bool PKS = sizeof(T) == 2;
+    constexpr bool PACKED = std::is_same<AT, int>::value;
+    const AT BIG = Elem<T>::big();
+    const AT d_a = (AT)bA[sa]; // c[a][succ a]
+    constexpr bool blocks = BLOCKS;
+    const int NB = (n + 64 * V - 1) / (64 * V);
+    const int blka = a / (64 * V);
+    const int lo = a + 1 == n ? 0 : a + 1;
+    const int len = symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
+        if (w0 >= n) continue;                          // pad wave
+        bool clean, self = false;
+        if (blocks) {
+            const int blkb = w0 / (64 * V);
+            int d = blkb - blka;
+            if (d < 0) d += NB;
+            self = d == 0;
+            if (!self && !(2 * d < NB || (2 * d == NB && blka < blkb))) continue;   // the other orientation's
+            clean = !self && (!PKS || w0 + 64 * V <= n);   // packed state has no poison for pad lanes
+        } else {
+            int t0 = w0 - lo;
+            if (t0 < 0) t0 += n;
+            const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
+            if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
+            clean = nowrap && t0 + 64 * V <= len && (unsigned)(am - w0) >= (unsigned)(64 * V) &&
+                    (unsigned)(a - w0) >= (unsigned)(64 * V) && (unsigned)(sa - w0) >= (unsigned)(64 * V);
+        }
+        const int b0 = (c * BT + tid) * V;
+        // all LDS reads of the chunk first (lanes past the row read its last vector), then the arithmetic
+        const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
+        auto valid = [&](int b) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(b));     // b < n is step-invariant: hoisted, it costs an SGPR pair per b
+            if (blocks) return ((b > a) | !self) & (b < n);
+            int tt = b - lo;
+            tt += (tt >> 31) & n;
+            return ((unsigned)tt < (unsigned)len) & (b != am) & (b != a) & (b != sa) & (b < n);
+        };
+        if constexpr (PKS) {
+            int g[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                unsigned addr;
+                asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                    : "=v"(addr) : "v"(ldsS), "v"(B.sb[c][v]));
+                g[v] = (int)*(const lds_u16 *)(uintptr_t)addr;
+            }
+            auto k32 = [&](auto check_tag) __attribute__((always_inline)) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                int m = 0x7fffffff;
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    int dl;
+                    const int made = (int)vget(xa, v) + g[v];
+                    asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                        : "=v"(dl) : "v"(made), "v"(B.sb[c][v]));
+                    if constexpr (CHECK) dl = valid(b0 + v) ? dl : MASKED32;
+                    if constexpr (TABU) dl = ((B.skm >> (c * V + v)) & 1u) ? MASKED32 : dl;
+                    m = min(m, (dl << 3) | v);
+                }
+                const int b = b0 + (m & 7);
+                const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                const long long key = (long long)(((u64)(unsigned)((m >> 3) - d_a) << 32) | lohi);
+                q.k = key < q.k ? key : q.k;
+            };
+            if (clean) k32(std::false_type{}); else k32(std::true_type{});
+        } else if constexpr (PACKED) {
+            AT g[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + B.sb[c][v]);
+            // groups of 4 independent keys + a min tree each: short dependency chains, and the
+            // only serial dependency on the running best is one compare per chunk
+            auto keys = [&](auto check_tag) __attribute__((always_inline)) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                constexpr int GR = V < 4 ? V : 4;
+                long long acc = 0x7fffffffffffffffll;
+#pragma unroll
+                for (int v0 = 0; v0 < V; v0 += GR) {
+                    long long key[GR];
+#pragma unroll
+                    for (int u = 0; u < GR; u++) {
+                        const int v = v0 + u;
+                        const int b = b0 + v;
+                        int delta = (int)vget(xa, v) + g[v] - (d_a + B.dn[c][v]);
+                        if constexpr (CHECK) delta = valid(b) ? delta : BIG;
+                        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                        key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
+                    }
+#pragma unroll
+                    for (int w = GR / 2; w >= 1; w /= 2)
+#pragma unroll
+                        for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
+                    acc = key[0] < acc ? key[0] : acc;
+                }
+                q.k = acc < q.k ? acc : q.k;
+            };
+            if (clean) keys(std::false_type{}); else keys(std::true_type{});
+        } else {
+            AT g[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + B.sb[c][v]);
+            auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
+            constexpr bool CHECK = decltype(check_tag)::value;
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const int b = b0 + v;
+                bool ok = true;
+                if constexpr (CHECK) ok = valid(b);
+                const AT made = (AT)vget(xa, v) + g[v];
+                const AT kept = d_a + B.dn[c][v];
+                const AT delta = made - kept;               // refinment.c:58-60
+                const bool lt = ok & (delta < q.d);
+                bool eq = ok & (delta == q.d);
+                if constexpr (!TABU) eq &= delta < (AT)0;
+                if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
+                    if (eq) {
+                        const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
+                        const u64 ko = q.a < q.b ? ((u64)(unsigned)q.a << 32) | (unsigned)q.b
+                                                 : ((u64)(unsigned)q.b << 32) | (unsigned)q.a;
+                        if (!q.have || kn < ko) { q.a = a; q.b = b; q.have = true; }
+                    }
+                }
+                q.d = lt ? delta : q.d;
+                q.a = lt ? a : q.a;
+                q.b = lt ? b : q.b;
+                q.have = q.have | lt;
+            }
+            };
+            if (clean) pairs(std::false_type{}); else pairs(std::true_type{});
+        }
+    }
+}
+
+template <typename T, int NCH, bool TABU>
+__device__ __forceinline__ void sweep_step(Best &q, const BState<T, NCH> &B, const T *bA, const unsigned char *bS, unsigned ldsS,
+                                           int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric)
+{
+    if constexpr (TABU) sweep_step_as<T, NCH, TABU, false>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, symmetric);
+    else if (symmetric) sweep_step_as<T, NCH, false, true>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true);
+    else sweep_step_as<T, NCH, false, false>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, false);
+}
+
+// the thread's result as (delta, key) for block_argmin
+template <typename T, bool TABU>
+__device__ __forceinline__ void best_finish(const Best &q, double &d, u64 &key)
+{
+    typedef typename Elem<T>::acc AT;
+    constexpr bool PKS = sizeof(T) == 2;
+    constexpr bool PACKED = std::is_same<AT, int>::value;
+    const double masked = PKS ? (double)(MASKED32 / 2) : (double)Elem<T>::big() / 2;
+    double bd = q.d;
+    int ba = q.a, bb = q.b;
+    bool have = q.have;
+    if constexpr (PACKED) {
+        const int di = (int)(q.k >> 32);
+        bd = (double)di;
+        ba = (int)(((unsigned)q.k) >> 16);
+        bb = (int)(((unsigned)q.k) & 0xffffu);
+        have = TABU ? bd < masked : di < 0;
+    }
+    // a masked pair can only have "won" in TABU mode (nothing admissible): report none
+    if (!have || bd >= masked) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else { d = bd; key = ba < bb ? ((u64)(unsigned)ba << 32) | (unsigned)bb : ((u64)(unsigned)bb << 32) | (unsigned)ba; }
+}
+
+// ---------------------------------------------------------------------------
 // K2 "pipelined" sweep: the streaming form for rows that fit LDS three times (any cell type;
 // uint16 rows up to n ~ 27 000).  Workgroup g owns a run of cnt consecutive tour edges and
 // needs the cnt+1 matrix rows of the nodes on that run, each exactly once:
-//     row r   (node a)  : c[a][b], read conflict-free from LDS at the thread's
-//                         OWN b's (b fixed per thread for the whole kernel, so
-//                         succ b and c[b][succ b] live in registers)
+//     row r   (node a)  : c[a][b], read conflict-free from LDS at the thread's OWN b's
 //     row r+1 (node sa) : c[sa][succ b], random LDS gather
 //     rows r+2 .. r+1+D : in flight from HBM in D register sets; one of them is
 //                         written to the third LDS buffer at the end of a step
 //                         and its registers are re-issued for row r+2+D
 // so every matrix byte is fetched once per sweep (+1 row per run) with 16-byte
 // coalesced loads, up to D rows per workgroup are in flight at any time, and
-// one barrier separates steps.  Both orientations of a pair meet in LDS;
-// pair_owned() keeps one.  The three pairs the reference skips (refinment.c:55: b == a,
-// b == succ a, succ b == a, i.e. b in {a_s, a_s+1, a_s-1}) are masked per WAVE: a wave whose
-// b range holds none of the three nodes (a scalar test) runs the unmasked variant.
+// one barrier separates steps.  State, pair ownership and argmin: sweep_step().
 // ---------------------------------------------------------------------------
 template <typename T, int NCH, int D, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
@@ -597,6 +838,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)) + 1; // nodes[-1] = node before the run
     const size_t nodes_bytes = (size_t)((A.P + 2 + 3) & ~3) * 4;
     Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes + 16);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;   // LDS byte address of the row buffers
 
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
@@ -614,19 +856,9 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
     for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
 
-    // per-thread state of the owned b's: LDS byte offset of succ b, and c[b][succ b].
-    // A b that can never be part of a move from this thread (pad lane, tabu) gets the poison
-    // value instead, which drives every delta it takes part in far above any real one.
-    // uint16 cells: the LDS byte offset of succ b (< 2 ld <= 65534) and c[b][succ b] share ONE
-    // register per b, low / high half (half the registers; the halves are SDWA operands, so
-    // unpacking is free).  No poison value exists then: tabu b's are a bit mask and pad lanes
-    // only ever meet the masked variant.
-    constexpr bool PKS = sizeof(T) == 2;
-    const AT BIG = Elem<T>::big();
-    constexpr int MASKED32 = 1 << 27;   // masked pair on the 32-bit key path: (x << 3) must not overflow
-    int sboff[NCH][V];
-    AT dnv[PKS ? 1 : NCH][PKS ? 1 : V];
-    unsigned skm = 0;
+    // per-thread state of the owned b's from the node-indexed view (coalesced 16-byte loads)
+    BState<T, NCH> B;
+    B.skm = 0;
     {
         const int *succ = A.S.succ + (size_t)t * n;
         const AT *dnb = dnb_of<AT>(A.S, t, n);
@@ -644,13 +876,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
                 bool sk = b >= n;
                 if constexpr (TABU)
                     if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-                if constexpr (PKS) {
-                    sboff[c][v] = (sb * (int)sizeof(T)) | ((int)dv[v] << 16);
-                    if (TABU && sk) skm |= 1u << (c * V + v);
-                } else {
-                    sboff[c][v] = sb * (int)sizeof(T);
-                    dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
-                }
+                bstate_set<T, NCH>(B, c, v, sb, dv[v], sk, TABU);
             }
         }
     }
@@ -684,173 +910,20 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     STAMP(2);
 
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
-    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
-    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
-    constexpr bool PACKED = std::is_same<AT, int>::value;
-    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
-    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
-    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
-    bool have = false;
+    Best q;
+    best_init<TABU>(q);
 
-    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;   // LDS byte address of the row buffers
     auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
         const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
         const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
         const T *bA = buf + (size_t)(s % 3) * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
+        const unsigned ldsS = lds0 + (unsigned)(((s + 1) % 3) * ld) * (unsigned)sizeof(T);
         if (stamp && s == 10 && (tid & 63) == 0) stamp[32 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 entered
         bool live = A.ablate != 1;
         if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
-        if (live) {
-            const AT d_a = (AT)bA[sa]; // c[a][succ a]
-            // Which orientation of a pair evaluates it.  Symmetric matrix, plain 2-opt: by BLOCKS of
-            // 64 V node indices (= what one wave holds in one chunk).  Pair {a, b} in different
-            // blocks belongs to the orientation whose b block lies less than half way round the
-            // block circle ahead of a's block (exactly half way: to the lower block); inside a's
-            // own block to b > a.  So a wave is either wholly in, wholly out, or the one wave
-            // holding a's block -- no wave straddles a range boundary, and the b's of the two
-            // neighbours of a need no mask at all: their delta is exactly 0 (c[a][pa] + c[sa][a] -
-            // (c[a][sa] + c[pa][a]), IEEE addition commutes), never an improvement.
-            // Otherwise (caller matrix not symmetric: b > a; tabu: every admissible pair counts,
-            // also non-improving ones): the cyclic index range [lo, lo+len-1], masked per lane
-            // wherever a wave straddles its ends or holds one of the three nodes around a.
-            const bool blocks = A.symmetric && !TABU;
-            const int NB = (n + 64 * V - 1) / (64 * V);
-            const int blka = a / (64 * V);
-            const int lo = a + 1 == n ? 0 : a + 1;
-            const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
-                const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
-                if (w0 >= n) continue;                          // pad wave
-                bool clean, self = false;
-                if (blocks) {
-                    const int blkb = w0 / (64 * V);
-                    int d = blkb - blka;
-                    if (d < 0) d += NB;
-                    self = d == 0;
-                    if (!self && !(2 * d < NB || (2 * d == NB && blka < blkb))) continue;   // the other orientation's
-                    clean = !self && (!PKS || w0 + 64 * V <= n);   // packed uint16 state has no poison for pad lanes
-                } else {
-                    int t0 = w0 - lo;
-                    if (t0 < 0) t0 += n;
-                    const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
-                    if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
-                    // unmasked variant: wave entirely inside the owned range and none of the three
-                    // nodes around a among its b's
-                    clean = nowrap && t0 + 64 * V <= len && (unsigned)(am - w0) >= (unsigned)(64 * V) &&
-                            (unsigned)(a - w0) >= (unsigned)(64 * V) && (unsigned)(sa - w0) >= (unsigned)(64 * V);
-                }
-                const int b0 = (c * BT + tid) * V;
-                // all LDS reads of the chunk first (lanes past the row read its last vector;
-                // their dn is poisoned), then the arithmetic
-                const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
-                auto valid = [&](int b) __attribute__((always_inline)) {
-                    asm volatile("" : "+v"(b));     // b < n is step-invariant: hoisted, it costs an SGPR pair per b
-                    if (blocks) return ((b > a) | !self) & (b < n);
-                    int tt = b - lo;
-                    tt += (tt >> 31) & n;
-                    return ((unsigned)tt < (unsigned)len) & (b != am) & (b != a) & (b != sa) & (b < n);
-                };
-                if constexpr (PKS) {
-                    // uint16 cells.  Per pair: one SDWA add forms the gather address from the low
-                    // half of the packed register, one add and one SDWA subtract give
-                    // delta + c[a][sa] = c[a][b] + c[sa][sb] - c[b][sb] (19 bits), and the slot number v
-                    // goes into the three low bits: for a fixed a the labels (min(a,b), max(a,b)) of a
-                    // thread's eight consecutive b's ascend with v, so ONE 32-bit min per pair keeps
-                    // the reference's tie order.  c[a][sa] (uniform) comes off after the min; the
-                    // 64-bit key (delta, labels) is built once per chunk for the winner only.
-                    const unsigned rowS = lds0 + (unsigned)(((s + 1) % 3) * ld) * 2u;
-                    int g[V];
-#pragma unroll
-                    for (int v = 0; v < V; v++) {
-                        unsigned addr;
-                        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-                            : "=v"(addr) : "v"(rowS), "v"(sboff[c][v]));
-                        g[v] = (int)*(const lds_u16 *)(uintptr_t)addr;
-                    }
-                    auto k32 = [&](auto check_tag) __attribute__((always_inline)) {
-                        constexpr bool CHECK = decltype(check_tag)::value;
-                        int m = 0x7fffffff;
-#pragma unroll
-                        for (int v = 0; v < V; v++) {
-                            int dl;
-                            const int made = (int)vget(xa, v) + g[v];
-                            asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-                                : "=v"(dl) : "v"(made), "v"(sboff[c][v]));
-                            if constexpr (CHECK) dl = valid(b0 + v) ? dl : MASKED32;
-                            if constexpr (TABU) dl = ((skm >> (c * V + v)) & 1u) ? MASKED32 : dl;
-                            m = min(m, (dl << 3) | v);
-                        }
-                        const int b = b0 + (m & 7);
-                        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-                        const long long key = (long long)(((u64)(unsigned)((m >> 3) - d_a) << 32) | lohi);
-                        best_k = key < best_k ? key : best_k;
-                    };
-                    if (clean) k32(std::false_type{}); else k32(std::true_type{});
-                } else if constexpr (PACKED) {
-                    AT g[V];
-#pragma unroll
-                    for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
-                    // groups of 4 independent keys + a min tree each: short dependency chains, and the
-                    // only serial dependency on best_k is one compare per chunk
-                    auto keys = [&](auto check_tag) __attribute__((always_inline)) {
-                        constexpr bool CHECK = decltype(check_tag)::value;
-                        constexpr int GR = V < 4 ? V : 4;
-                        long long acc = 0x7fffffffffffffffll;
-#pragma unroll
-                        for (int v0 = 0; v0 < V; v0 += GR) {
-                            long long key[GR];
-#pragma unroll
-                            for (int u = 0; u < GR; u++) {
-                                const int v = v0 + u;
-                                const int b = b0 + v;
-                                int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
-                                if constexpr (CHECK) delta = valid(b) ? delta : BIG;
-                                const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-                                key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
-                            }
-#pragma unroll
-                            for (int w = GR / 2; w >= 1; w /= 2)
-#pragma unroll
-                                for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
-                            acc = key[0] < acc ? key[0] : acc;
-                        }
-                        best_k = acc < best_k ? acc : best_k;
-                    };
-                    if (clean) keys(std::false_type{}); else keys(std::true_type{});
-                } else {
-                    AT g[V];
-#pragma unroll
-                    for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
-#pragma unroll
-                    for (int v = 0; v < V; v++) {
-                        const int b = b0 + v;
-                        const bool ok = clean || valid(b);
-                        const AT made = (AT)vget(xa, v) + g[v];
-                        const AT kept = d_a + dnv[c][v];
-                        const AT delta = made - kept;               // refinment.c:58-60
-                        const bool lt = ok & (delta < best_d);
-                        bool eq = ok & (delta == best_d);
-                        if constexpr (!TABU) eq &= delta < (AT)0;
-                        if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
-                            if (eq) {
-                                const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
-                                const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
-                                                               : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
-                                if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
-                            }
-                        }
-                        best_d = lt ? delta : best_d;
-                        best_a = lt ? a : best_a;
-                        best_b = lt ? b : best_b;
-                        have = have | lt;
-                    }
-                }
-            }
-        }
+        if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
         if (stamp && tid == 0 && s < 12) stamp[8 + 2 * s] = wall_clock64();      // compute done
         if (stamp && s == 10 && (tid & 63) == 0) stamp[48 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 evaluated
         if (s + 2 <= cnt) land(Rs, (s + 2) % 3);
@@ -871,17 +944,9 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     }
 
     STAMP(3);
-    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
-    if constexpr (PACKED) {
-        best_d = (AT)(int)(best_k >> 32);
-        best_a = (int)(((unsigned)best_k) >> 16);
-        best_b = (int)(((unsigned)best_k) & 0xffffu);
-        have = TABU ? best_d < MASKED32 / 2 : best_d < 0;
-    }
-    double d = (double)best_d;
+    double d;
     u64 key;
-    if (!have || best_d >= (PKS ? (AT)(MASKED32 / 2) : BIG / 2)) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
-    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    best_finish<T, TABU>(q, d, key);
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
@@ -892,15 +957,13 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 
 
 // ---------------------------------------------------------------------------
-// K2/K3 "resident" sweep: for rows small enough that the P+1 (<= 9) rows of a run fit LDS
+// K3 "resident" sweep: for rows small enough that the P+1 (<= 9) rows of a run fit LDS
 // together (uint16 cells up to n ~ 9 000 at one workgroup per CU, int32 / f64 for small n
-// and for multi-start batches).  The workgroup fetches all its rows at once (every load in
-// flight together: one memory round trip for the whole run), lands them, and after ONE
-// barrier each wave walks the run's steps on its own -- no barrier, no LDS write and no
-// global access inside the step loop.  The three pairs refinment.c:55 skips are masked
-// from registers: a thread knows, for each of its own b's, which step index j (if any) has
-// b as its node a_j, and pair (a_s, b) is invalid exactly when |s - j| <= 1.
-// Same pair ownership, argmin key and arithmetic as k_sweep_pipe.
+// and for multi-start batches).  The workgroup issues the loads of all its rows at once (one
+// memory round trip for the whole run), lands them in chunks of three rows, and after each
+// chunk's barrier every wave walks the steps whose two rows are in LDS on its own -- no
+// barrier, no LDS write and no global access inside a step.  State, pair ownership and
+// argmin: sweep_step().
 // ---------------------------------------------------------------------------
 template <typename T, int NCH, int PMAX, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
@@ -920,11 +983,10 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     const size_t rows_bytes = (size_t)(A.P + 1) * ld * sizeof(T);
     int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
     Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;
 
     const T *mat = static_cast<const T *>(A.mat);
     const int *ord = A.S.ord + (size_t)t * n;
-    const int *pos = A.S.pos + (size_t)t * n;
-    const AT *dp = dpos_of<AT>(A.S, t, n);
     const int dir = A.S.dir[t];
 
     int iter = 0, tenure = 0;
@@ -941,33 +1003,27 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     // per-thread state of the owned b's: coalesced loads of the node-indexed view.  Issued
     // BEFORE the matrix rows: vector loads return in order, so anything younger than the rows
     // would only become usable after the last row has arrived.
-    const int *succ = A.S.succ + (size_t)t * n;
-    const AT *dnb = dnb_of<AT>(A.S, t, n);
-    const AT BIG = Elem<T>::big();
-    int sboff[NCH][V], jb[NCH][V];
-    AT dnv[NCH][V];
+    BState<T, NCH> B;
+    B.skm = 0;
+    {
+        const int *succ = A.S.succ + (size_t)t * n;
+        const AT *dnb = dnb_of<AT>(A.S, t, n);
 #pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int b0 = min((c * BT + tid) * V, ld - V);   // lanes past the row: masked below
-        int qv[V], sv[V];
-        AT dv[V];
-        load_run<V>(pos + b0, qv);
-        load_run<V>(succ + b0, sv);
-        load_run<V>(dnb + b0, dv);
+        for (int c = 0; c < NCH; c++) {
+            const int b0 = min((c * BT + tid) * V, ld - V);   // lanes past the row: masked
+            int sv[V];
+            AT dv[V];
+            load_run<V>(succ + b0, sv);
+            load_run<V>(dnb + b0, dv);
 #pragma unroll
-        for (int v = 0; v < V; v++) {
-            const int b = (c * BT + tid) * V + v;
-            const int qb = qv[v], sb = b < n ? sv[v] : 0;
-            bool sk = b >= n;
-            if constexpr (TABU)
-                if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-            sboff[c][v] = sb * (int)sizeof(T);
-            dnv[c][v] = sk ? -BIG : dv[v];   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
-            // step index whose node a_j is b (run positions p0 .. p0+cnt, walked along dir), else far away
-            int j = dir > 0 ? qb - p0 : p0 + cnt - qb;
-            if (j < -1) j += n;              // the run may wrap past position n-1 / below 0
-            if (j > n - 2) j -= n;
-            jb[c][v] = ((b < n && j >= -1 && j <= cnt) ? j : 1 << 20) - 1;   // invalid steps: jb .. jb+2
+            for (int v = 0; v < V; v++) {
+                const int b = (c * BT + tid) * V + v;
+                const int sb = b < n ? sv[v] : 0;
+                bool sk = b >= n;
+                if constexpr (TABU)
+                    if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
+                bstate_set<T, NCH>(B, c, v, sb, dv[v], sk, TABU);
+            }
         }
     }
     __syncthreads(); // nodes[] visible
@@ -985,107 +1041,20 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     }
 
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
-    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
-    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
-    constexpr bool PACKED = std::is_same<AT, int>::value;
-    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
-    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
-    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
-    bool have = false;
+    Best q;
+    best_init<TABU>(q);
 
     auto step = [&](int s) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
         const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
         const T *bA = rows + (size_t)s * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
+        const unsigned ldsS = lds0 + (unsigned)((s + 1) * ld) * (unsigned)sizeof(T);
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         bool live = A.ablate != 1;
         if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
-        if (!live) return;
-        const AT d_a = (AT)bA[sa];            // c[a][succ a]
-        // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
-        const int lo = a + 1 == n ? 0 : a + 1;
-        const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
-            if (w0 >= n) continue;                          // pad wave
-            int t0 = w0 - lo;
-            if (t0 < 0) t0 += n;
-            const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
-            const bool inside = nowrap && t0 + 64 * V <= len;
-            if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
-            const int b0 = (c * BT + tid) * V;
-            const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
-            AT g[V];
-#pragma unroll
-            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
-            if constexpr (PACKED) {
-                // groups of 4 independent keys + a min tree each: short dependency chains, and the
-                // only serial dependency on best_k is one compare per chunk
-                auto keys = [&](auto check_tag) __attribute__((always_inline)) {
-                    constexpr bool CHECK = decltype(check_tag)::value;
-                    constexpr int GR = V < 4 ? V : 4;
-                    long long acc = 0x7fffffffffffffffll;
-#pragma unroll
-                    for (int v0 = 0; v0 < V; v0 += GR) {
-                        long long key[GR];
-#pragma unroll
-                        for (int u = 0; u < GR; u++) {
-                            const int v = v0 + u;
-                            const int b = b0 + v;
-                            bool ok = (unsigned)(s - jb[c][v]) > 2u;   // not b in {pred a, a, succ a}
-                            if constexpr (CHECK) {
-                                int tt = b - lo;
-                                tt += (tt >> 31) & n;
-                                ok &= (unsigned)tt < (unsigned)len;
-                            }
-                            int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
-                            delta = ok ? delta : BIG;
-                            const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-                            key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
-                        }
-#pragma unroll
-                        for (int w = GR / 2; w >= 1; w /= 2)
-#pragma unroll
-                            for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
-                        acc = key[0] < acc ? key[0] : acc;
-                    }
-                    best_k = acc < best_k ? acc : best_k;
-                };
-                if (inside) keys(std::false_type{}); else keys(std::true_type{});
-            } else {
-#pragma unroll
-                for (int v = 0; v < V; v++) {
-                    const int b = b0 + v;
-                    bool ok = (unsigned)(s - jb[c][v]) > 2u;       // not b in {pred a, a, succ a}
-                    if (!inside) {
-                        int tt = b - lo;
-                        tt += (tt >> 31) & n;
-                        ok &= (unsigned)tt < (unsigned)len;
-                    }
-                    const AT made = (AT)vget(xa, v) + g[v];
-                    const AT kept = d_a + dnv[c][v];
-                    const AT delta = made - kept;               // refinment.c:58-60
-                    const bool lt = ok & (delta < best_d);
-                    bool eq = ok & (delta == best_d);
-                    if constexpr (!TABU) eq &= delta < (AT)0;
-                    if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
-                        if (eq) {
-                            const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
-                            const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
-                                                           : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
-                            if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
-                        }
-                    }
-                    best_d = lt ? delta : best_d;
-                    best_a = lt ? a : best_a;
-                    best_b = lt ? b : best_b;
-                    have = have | lt;
-                }
-            }
-        }
+        if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
     };
 
     // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
@@ -1111,17 +1080,9 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     }
 
     STAMP(3);
-    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
-    if constexpr (PACKED) {
-        best_d = (AT)(int)(best_k >> 32);
-        best_a = (int)(((unsigned)best_k) >> 16);
-        best_b = (int)(((unsigned)best_k) & 0xffffu);
-        have = TABU ? best_d < BIG / 2 : best_d < 0;
-    }
-    double d = (double)best_d;
+    double d;
     u64 key;
-    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
-    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    best_finish<T, TABU>(q, d, key);
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
@@ -1291,9 +1252,8 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // a node inside the reversed range swaps its left/right neighbour (and edge cost); the four
     // nodes around the range ends get one new neighbour.  No gather, no dependence on the move
     // beyond scalars.  The workgroup that owns a slice of b's also writes their new records.
-    const AT BIG = Elem<T>::big();
-    int sboff[NCH][V], jb[NCH][V];
-    AT dnv[NCH][V];
+    BState<T, NCH> B;
+    B.skm = 0;
     const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -1329,12 +1289,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
             }
             const int sb = b < n ? (ndir > 0 ? r2 : l2) : 0;
             const AT dn = ndir > 0 ? dr2 : dl2;
-            sboff[c][v] = sb * (int)sizeof(T);
-            dnv[c][v] = b >= n ? -BIG : dn;  // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
-            int j = ndir > 0 ? qn - p0 : p0 + cnt - qn;
-            if (j < -1) j += n;
-            if (j > n - 2) j -= n;
-            jb[c][v] = ((b < n && j >= -1 && j <= cnt) ? j : 1 << 20) - 1;   // invalid steps: jb .. jb+2
+            bstate_set<T, NCH>(B, c, v, sb, dn, b >= n, false);
         }
     }
     if (blockIdx.x == 0 && tid == 0) {                   // per-tour scalars of the new state
@@ -1364,105 +1319,20 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
 
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-    // Integer deltas (n < 65536): the whole argmin key (delta, min(a,b), max(a,b)) is ONE signed
-    // 64-bit word, delta in the high half, so "better" is a single compare and ties need no
-    // special path.  A masked pair gets delta = BIG.  Doubles keep (delta, a, b) + a tie branch.
-    constexpr bool PACKED = std::is_same<AT, int>::value;
-    long long best_k = TABU ? (long long)(((u64)0x7fffffffu << 32) | 0xffffffffu) : 0ll;  // (lim, none) / (0, no move)
-    AT best_d = TABU ? Elem<T>::lim() : (AT)0;
-    int best_a = 0, best_b = 0;               // (0,0): "no move"; cannot win a tie
-    bool have = false;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;
+    Best q;
+    best_init<false>(q);
 
     auto step = [&](int s) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
         const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
         const T *bA = rows + (size_t)s * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
+        const unsigned ldsS = lds0 + (unsigned)((s + 1) * ld) * (unsigned)sizeof(T);
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         if (A.ablate == 1) return;
-        const AT d_a = (AT)bA[sa];            // c[a][succ a]
-        // pairs owned by a's workgroup: b in the cyclic index range [lo, lo+len-1]
-        const int lo = a + 1 == n ? 0 : a + 1;
-        const int len = A.symmetric ? ((n & 1) ? (n - 1) / 2 : (a < n / 2 ? n / 2 : n / 2 - 1)) : n - 1 - a;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int w0 = (c * BT + wave_base) * V;        // this wave's first b in chunk c (scalar)
-            if (w0 >= n) continue;                          // pad wave
-            int t0 = w0 - lo;
-            if (t0 < 0) t0 += n;
-            const bool nowrap = t0 + 64 * V <= n && w0 + 64 * V <= n;
-            const bool inside = nowrap && t0 + 64 * V <= len;
-            if (nowrap && t0 >= len) continue;              // wave entirely outside: wave-uniform skip
-            const int b0 = (c * BT + tid) * V;
-            const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
-            AT g[V];
-#pragma unroll
-            for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + sboff[c][v]);
-            if constexpr (PACKED) {
-                // groups of 4 independent keys + a min tree each: short dependency chains, and the
-                // only serial dependency on best_k is one compare per chunk
-                auto keys = [&](auto check_tag) __attribute__((always_inline)) {
-                    constexpr bool CHECK = decltype(check_tag)::value;
-                    constexpr int GR = V < 4 ? V : 4;
-                    long long acc = 0x7fffffffffffffffll;
-#pragma unroll
-                    for (int v0 = 0; v0 < V; v0 += GR) {
-                        long long key[GR];
-#pragma unroll
-                        for (int u = 0; u < GR; u++) {
-                            const int v = v0 + u;
-                            const int b = b0 + v;
-                            bool ok = (unsigned)(s - jb[c][v]) > 2u;   // not b in {pred a, a, succ a}
-                            if constexpr (CHECK) {
-                                int tt = b - lo;
-                                tt += (tt >> 31) & n;
-                                ok &= (unsigned)tt < (unsigned)len;
-                            }
-                            int delta = (int)vget(xa, v) + g[v] - (d_a + dnv[c][v]);
-                            delta = ok ? delta : BIG;
-                            const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-                            key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
-                        }
-#pragma unroll
-                        for (int w = GR / 2; w >= 1; w /= 2)
-#pragma unroll
-                            for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
-                        acc = key[0] < acc ? key[0] : acc;
-                    }
-                    best_k = acc < best_k ? acc : best_k;
-                };
-                if (inside) keys(std::false_type{}); else keys(std::true_type{});
-            } else {
-#pragma unroll
-                for (int v = 0; v < V; v++) {
-                    const int b = b0 + v;
-                    bool ok = (unsigned)(s - jb[c][v]) > 2u;       // not b in {pred a, a, succ a}
-                    if (!inside) {
-                        int tt = b - lo;
-                        tt += (tt >> 31) & n;
-                        ok &= (unsigned)tt < (unsigned)len;
-                    }
-                    const AT made = (AT)vget(xa, v) + g[v];
-                    const AT kept = d_a + dnv[c][v];
-                    const AT delta = made - kept;               // refinment.c:58-60
-                    const bool lt = ok & (delta < best_d);
-                    bool eq = ok & (delta == best_d);
-                    if constexpr (!TABU) eq &= delta < (AT)0;
-                    if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
-                        if (eq) {
-                            const u64 kn = a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a;
-                            const u64 ko = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b
-                                                           : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
-                            if (!have || kn < ko) { best_a = a; best_b = b; have = true; }
-                        }
-                    }
-                    best_d = lt ? delta : best_d;
-                    best_a = lt ? a : best_a;
-                    best_b = lt ? b : best_b;
-                    have = have | lt;
-                }
-            }
-        }
+        sweep_step_as<T, NCH, false, true>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true);
     };
 
     // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
@@ -1488,17 +1358,9 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
 
     STAMP(3);
-    // a poisoned pair can only have "won" in TABU mode (nothing admissible): report none
-    if constexpr (PACKED) {
-        best_d = (AT)(int)(best_k >> 32);
-        best_a = (int)(((unsigned)best_k) >> 16);
-        best_b = (int)(((unsigned)best_k) & 0xffffu);
-        have = TABU ? best_d < BIG / 2 : best_d < 0;
-    }
-    double d = (double)best_d;
+    double d;
     u64 key;
-    if (!have || best_d >= BIG / 2) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
-    else key = best_a < best_b ? ((u64)(unsigned)best_a << 32) | (unsigned)best_b : ((u64)(unsigned)best_b << 32) | (unsigned)best_a;
+    best_finish<T, false>(q, d, key);
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
