@@ -1149,6 +1149,22 @@ __global__ void __launch_bounds__(256) k_fused_end(Tours S, Fused F, int n, int 
     if (v == 0) { S.dir[t] = dir; S.cost[t] = F.cost[c][t]; }
 }
 
+// Wave-uniform reads of the previous launch's state go through the scalar cache (constant
+// address space: the compiler emits s_load and tracks lgkmcnt): every wave holds them in SGPRs,
+// no LDS staging, no vector-memory queueing.
+typedef __attribute__((address_space(4))) const int c_i32;
+typedef __attribute__((address_space(4))) const double c_f64;
+template <typename T>
+__device__ __forceinline__ typename Elem<T>::acc scalar_cell(const T *mat, size_t idx)
+{
+    if constexpr (sizeof(T) == 8) return ((c_f64 *)mat)[idx];
+    else if constexpr (sizeof(T) == 4) return ((c_i32 *)mat)[idx];
+    else {
+        const unsigned w = (unsigned)((c_i32 *)mat)[idx >> 1];
+        return (int)((idx & 1) ? w >> 16 : w & 0xffffu);
+    }
+}
+
 template <typename T, int NCH, int PMAX>
 __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 {
@@ -1175,9 +1191,25 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int *ord_o = A.F.ord[rd] + tn, *pos_o = A.F.pos[rd] + tn;
     const int *nl_o = A.F.nl[rd] + tn, *nr_o = A.F.nr[rd] + tn;
     const AT *dl_o = reinterpret_cast<const AT *>(A.F.dl[rd] + tn), *dr_o = reinterpret_cast<const AT *>(A.F.dr[rd] + tn);
-    const int k_done = A.F.k[rd][t];                   // sweeps completed before this launch
-    const int dir_o = A.F.dir[rd][t];
+    c_i32 *ord_c = (c_i32 *)ord_o, *pos_c = (c_i32 *)pos_o;
+    const int k_done = ((c_i32 *)A.F.k[rd])[t];        // sweeps completed before this launch
+    const int dir_o = ((c_i32 *)A.F.dir[rd])[t];
+    const int stop_o = ((c_i32 *)A.F.stop[rd])[t];
     const int cap = A.S.cap_sweeps[t];
+    const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
+    const Partial pq0 = part[min((int)threadIdx.x, (int)gridDim.x - 1)];   // issued before k_done is back: one trip less
+    // the old records of the own b's depend on nothing either: in flight during the reduction
+    int qv[NCH][V], lv[NCH][V], rv[NCH][V];
+    AT dlv[NCH][V], drv[NCH][V];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int b0 = min((c * (int)blockDim.x + (int)threadIdx.x) * V, ld - V);
+        load_run<V>(pos_o + b0, qv[c]);
+        load_run<V>(nl_o + b0, lv[c]);
+        load_run<V>(nr_o + b0, rv[c]);
+        load_run<V>(dl_o + b0, dlv[c]);
+        load_run<V>(dr_o + b0, drv[c]);
+    }
 
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
@@ -1187,8 +1219,8 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     double md = 0.0;
     u64 mkey = 0;
     if (k_done > 0) {
-        const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
-        for (int g = tid; g < (int)gridDim.x; g += BT) {
+        if (tid < (int)gridDim.x) { md = pq0.d; mkey = pq0.key; }
+        for (int g = tid + BT; g < (int)gridDim.x; g += BT) {     // more workgroups than threads: not with the default plans
             const Partial q = part[g];
             if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; }
         }
@@ -1196,14 +1228,14 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
     const unsigned long long t_red = stamp ? wall_clock64() : 0ull;
     const bool move = k_done > 0 && md < TWO_OPT_EPS;
-    if (A.F.stop[rd][t] || (k_done > 0 && !move)) {
+    if (stop_o || (k_done > 0 && !move)) {
         // either the previous launch applied the last move a sweep cap allows, or the previous
         // sweep was the final, non-improving one: the state that launch left is the result.
         // (Every workgroup leaves here without writing, so a workgroup that starts after
         // workgroup 0 has raised `done` behaves the same.)
         if (blockIdx.x == 0 && tid == 0) {
             A.S.done[t] = 1; A.F.cur[t] = rd; A.S.nsweeps[t] = k_done;
-            if (!A.F.stop[rd][t]) {
+            if (!stop_o) {
                 A.S.last_delta[t] = md;
                 if (t == 0 && k_done <= A.hist.cap) { A.hist.a[k_done - 1] = -1; A.hist.b[k_done - 1] = -1; A.hist.d[k_done - 1] = md; }
             }
@@ -1211,14 +1243,14 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         return;
     }
     const bool last = cap >= 0 && k_done >= cap;     // apply this move, then stop sweeping
-    const int ma = (int)(mkey >> 32), mb = (int)(mkey & 0xffffffffu);
+    const int ma = __builtin_amdgcn_readfirstlane((int)(mkey >> 32)), mb = __builtin_amdgcn_readfirstlane((int)(mkey & 0xffffffffu));
 
     // ---- the move as an array operation on the OLD state (see Tours): reverse cells [lo, lo+M-1]
     int lo = 0, M = 0, ndir = dir_o;
     int x0 = -1, x1 = -1, x2 = -1, x3 = -1;
     AT wA = 0, wB = 0;
     if (move) {
-        const int i = pos_o[ma], j = pos_o[mb];
+        const int i = pos_c[ma], j = pos_c[mb];
         int L = (j - i) * dir_o;
         if (L < 0) L += n;
         const bool other = n - L < L;
@@ -1226,10 +1258,10 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         const int first = other ? wrap(j + dir_o, n) : wrap(i + dir_o, n);
         lo = dir_o > 0 ? first : wrap(first - (M - 1), n);
         if (other) ndir = -dir_o;
-        x0 = ord_o[wrap(lo - 1, n)]; x1 = ord_o[lo];
-        x2 = ord_o[wrap(lo + M - 1, n)]; x3 = ord_o[wrap(lo + M, n)];
-        wA = (AT)mat[(size_t)x0 * ld + x2];            // the two new edges {a,b}, {succ a, succ b}
-        wB = (AT)mat[(size_t)x1 * ld + x3];
+        x0 = ord_c[wrap(lo - 1, n)]; x1 = ord_c[lo];
+        x2 = ord_c[wrap(lo + M - 1, n)]; x3 = ord_c[wrap(lo + M, n)];
+        wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
+        wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
     }
     auto new_cell = [&](int p) __attribute__((always_inline)) {   // old cell holding what cell p holds after the move
         int r = p - lo;
@@ -1257,25 +1289,17 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
-        const int b0 = min((c * BT + tid) * V, ld - V);
-        int qv[V], lv[V], rv[V];
-        AT dlv[V], drv[V];
-        load_run<V>(pos_o + b0, qv);
-        load_run<V>(nl_o + b0, lv);
-        load_run<V>(nr_o + b0, rv);
-        load_run<V>(dl_o + b0, dlv);
-        load_run<V>(dr_o + b0, drv);
         const int ub0 = (c * BT + tid) * V;
         const bool mine = ub0 < n && ub0 / slice == (int)blockIdx.x;
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int b = (c * BT + tid) * V + v;
-            int r = qv[v] - lo;
+            int r = qv[c][v] - lo;
             if (r < 0) r += n;
             const bool inr = r < M;
-            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[v];
-            int l2 = inr ? rv[v] : lv[v], r2 = inr ? lv[v] : rv[v];
-            AT dl2 = inr ? drv[v] : dlv[v], dr2 = inr ? dlv[v] : drv[v];
+            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[c][v];
+            int l2 = inr ? rv[c][v] : lv[c][v], r2 = inr ? lv[c][v] : rv[c][v];
+            AT dl2 = inr ? drv[c][v] : dlv[c][v], dr2 = inr ? dlv[c][v] : drv[c][v];
             if (move) {
                 if (b == x0) { r2 = x2; dr2 = wA; }
                 if (b == x3) { l2 = x1; dl2 = wB; }
