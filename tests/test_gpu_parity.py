@@ -138,8 +138,8 @@ def fused(request, eng, T):
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "n64_s7", "n200_s3"])
 def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel, fused):
     """every sweep picks the reference's (a,b) and leaves the reference's tour"""
-    if fused and kernel != 3:
-        pytest.skip("the fused path exists for the resident kernel only")
+    if fused and kernel not in (2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
     xy, c = setup(eng, T, O, instances, name, elem, kernel)
     succ, cost = O.nn_tour(c, 0)
     g = succ.copy(); gcost = cost
@@ -155,8 +155,8 @@ def test_two_opt_once_trajectory(eng, T, O, instances, name, elem, kernel, fused
 @pytest.mark.parametrize("elem,kernel", COMBOS)
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123", "n1024_s1"])
 def test_two_opt_to_local_optimum_golden(eng, T, O, instances, golden, name, elem, kernel, fused):
-    if fused and kernel != 3:
-        pytest.skip("the fused path exists for the resident kernel only")
+    if fused and kernel not in (2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
     xy, c = setup(eng, T, O, instances, name, elem, kernel)
     g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
     succ, nn_cost = eng.nn_tour(0)
@@ -202,10 +202,10 @@ def test_full_size_fnl4461(eng, T, O, golden, elem):
     assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
 
 
-@pytest.mark.parametrize("elem,kernel", [(0, 0), (1, 0), (2, 0), (2, 1), (2, 3), (3, 0), (3, 1)])
+@pytest.mark.parametrize("elem,kernel", [(0, 0), (1, 0), (1, 2), (2, 0), (2, 1), (2, 2), (2, 3), (3, 0), (3, 1), (3, 2)])
 def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
-    if fused and kernel not in (0, 3):
-        pytest.skip("the fused path exists for the resident kernel only")
+    if fused and kernel not in (0, 2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
     """the configuration BASELINE.json's metric is quoted on: -n 4096 -seed 123, NN(0) then
     609 sweeps to 488522 (reference: 48.7 s on one core)"""
     g = golden["random"]["n4096_s123"]
@@ -217,6 +217,32 @@ def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
     cost, sweeps, _ = eng.two_opt(succ)
     assert (sweeps, cost, fx(O, succ)) == (g["two_opt"]["sweeps"], g["two_opt"]["final_cost"], g["two_opt"]["final_fnv"])
     assert O.valid_tour(succ)
+
+
+def test_n16384_first_sweeps(eng, T, O, fused):
+    """the large size of the throughput table (uint16 rows of 32 KB: pipelined kernel, two chunks
+    per thread): NN(0) and the first sweeps against the oracle, move by move"""
+    n = 16384
+    xy = O.random_points(n, 123)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, 0)
+    eng.tour_nn(0, 0)
+    g, gcost, _ = eng.tour_store(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    eng.set_option(T.OPT_HISTORY, 64)
+    K = 6
+    want = []
+    for _ in range(K):
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        want.append((min(mv), max(mv), float(d)))
+    sweeps, _ = eng.tour_two_opt(0, max_sweeps=K)
+    g, gcost, _ = eng.tour_store(0)
+    assert sweeps == K and gcost == cost and np.array_equal(g, succ)
+    ha, hb, hd = eng.history(K)
+    assert [(int(min(a, b)), int(max(a, b)), float(d)) for a, b, d in zip(ha, hb, hd)] == want
+    assert eng.info()["kernel"] == 2
 
 
 def test_d18512_five_sweeps(eng, T, O, golden):

@@ -9,9 +9,11 @@ from bench import reference_points
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 elem = {"u16": T.ELEM_U16, "i32": T.ELEM_I32, "f64": T.ELEM_F64, "auto": T.ELEM_AUTO}[
     next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--elem=")), "auto")]
+kernel = int(next((a.split("=")[1] for a in sys.argv[1:] if a.startswith("--kernel=")), "0"))
 for n in [int(a) for a in args]:
     eng = T.Engine(0)
     eng.set_option(T.OPT_ELEM, elem)
+    eng.set_option(T.OPT_KERNEL, kernel)
     eng.set_points(reference_points(n, 123)); eng.build_costs(); eng.tour_nn(0, 0)
     eng.set_option(T.OPT_FUSED, 0)
     ms = eng.time_sweep(0, 30)

@@ -820,6 +820,80 @@ __device__ __forceinline__ void best_finish(const Best &q, double &d, u64 &key)
 // coalesced loads, up to D rows per workgroup are in flight at any time, and
 // one barrier separates steps.  State, pair ownership and argmin: sweep_step().
 // ---------------------------------------------------------------------------
+// The streaming part of the pipelined sweep (after nodes[] and the per-b state are in place):
+// rows through D register sets and three rotating LDS buffers, one barrier per step.
+template <typename T, int NCH, int D, bool TABU>
+__device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
+                                            int cnt, int iter, int tenure, unsigned long long *stamp)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    const int n = A.n, ld = A.ld;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V;
+    const T *mat = static_cast<const T *>(A.mat);
+#define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
+    VT R[D][NCH];
+    auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        // Branch-free.  Lanes past the row end re-read its last vector (and later re-write
+        // the same bytes).  Past the end of the run (r > cnt) every lane re-reads one hot
+        // vector instead: the number of loads in flight is then the same on every path,
+        // which lets hipcc place exact counted vmcnt waits in front of the LDS writes.
+        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
+        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
+    };
+    auto land = [&](const VT(&Rs)[NCH], int slot) __attribute__((always_inline)) {
+        VT *dst = reinterpret_cast<VT *>(buf + (size_t)slot * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
+    };
+    // row r travels through register set r % D
+#pragma unroll
+    for (int r = 0; r < D; r++) issue(R[r], r);
+    land(R[0], 0);
+    land(R[1 % D], 1);
+    issue(R[0], D);
+    issue(R[1 % D], D + 1);
+    __syncthreads();
+    STAMP(2);
+
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+
+    auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const T *bA = buf + (size_t)(s % 3) * ld;
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
+        const unsigned ldsS = lds0 + (unsigned)(((s + 1) % 3) * ld) * (unsigned)sizeof(T);
+        if (stamp && s == 10 && (tid & 63) == 0) stamp[32 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 entered
+        bool live = A.ablate != 1;
+        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
+        if (stamp && tid == 0 && s < 12) stamp[8 + 2 * s] = wall_clock64();      // compute done
+        if (stamp && s == 10 && (tid & 63) == 0) stamp[48 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 evaluated
+        if (s + 2 <= cnt) land(Rs, (s + 2) % 3);
+        issue(Rs, s + 2 + D);
+        __syncthreads();
+        if (stamp && tid == 0 && s < 12) stamp[9 + 2 * s] = wall_clock64();      // row landed, barrier passed
+    };
+
+    {
+        int s = 0;
+        for (; s + D <= cnt; s += D) { // unconditional body: exact vmcnt accounting
+#pragma unroll
+            for (int u = 0; u < D; u++) step(s + u, R[(u + 2) % D]);
+        }
+#pragma unroll
+        for (int u = 0; u < D; u++)
+            if (s + u < cnt) step(s + u, R[(u + 2) % D]);
+    }
+
+#undef STAMP
+}
+
 template <typename T, int NCH, int D, bool TABU>
 __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 {
@@ -883,65 +957,9 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     __syncthreads(); // nodes[] visible
     STAMP(1);
 
-    VT R[D][NCH];
-    auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
-        // Branch-free.  Lanes past the row end re-read its last vector (and later re-write
-        // the same bytes).  Past the end of the run (r > cnt) every lane re-reads one hot
-        // vector instead: the number of loads in flight is then the same on every path,
-        // which lets hipcc place exact counted vmcnt waits in front of the LDS writes.
-        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
-        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
-    };
-    auto land = [&](const VT(&Rs)[NCH], int slot) __attribute__((always_inline)) {
-        VT *dst = reinterpret_cast<VT *>(buf + (size_t)slot * ld);
-#pragma unroll
-        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
-    };
-    // row r travels through register set r % D
-#pragma unroll
-    for (int r = 0; r < D; r++) issue(R[r], r);
-    land(R[0], 0);
-    land(R[1 % D], 1);
-    issue(R[0], D);
-    issue(R[1 % D], D + 1);
-    __syncthreads();
-    STAMP(2);
-
-    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     Best q;
     best_init<TABU>(q);
-
-    auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
-        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
-        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
-        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
-        const T *bA = buf + (size_t)(s % 3) * ld;
-        const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
-        const unsigned ldsS = lds0 + (unsigned)(((s + 1) % 3) * ld) * (unsigned)sizeof(T);
-        if (stamp && s == 10 && (tid & 63) == 0) stamp[32 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 entered
-        bool live = A.ablate != 1;
-        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
-        if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
-        if (stamp && tid == 0 && s < 12) stamp[8 + 2 * s] = wall_clock64();      // compute done
-        if (stamp && s == 10 && (tid & 63) == 0) stamp[48 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 evaluated
-        if (s + 2 <= cnt) land(Rs, (s + 2) % 3);
-        issue(Rs, s + 2 + D);
-        __syncthreads();
-        if (stamp && tid == 0 && s < 12) stamp[9 + 2 * s] = wall_clock64();      // row landed, barrier passed
-    };
-
-    {
-        int s = 0;
-        for (; s + D <= cnt; s += D) { // unconditional body: exact vmcnt accounting
-#pragma unroll
-            for (int u = 0; u < D; u++) step(s + u, R[(u + 2) % D]);
-        }
-#pragma unroll
-        for (int u = 0; u < D; u++)
-            if (s + u < cnt) step(s + u, R[(u + 2) % D]);
-    }
+    pipe_stream<T, NCH, D, TABU>(q, A, B, buf, nodes, lds0, cnt, iter, tenure, stamp);
 
     STAMP(3);
     double d;
@@ -1165,7 +1183,8 @@ __device__ __forceinline__ typename Elem<T>::acc scalar_cell(const T *mat, size_
     }
 }
 
-template <typename T, int NCH, int PMAX>
+// D = 0: rows resident (k_sweep_res's body, P <= PMAX); D > 0: rows streamed (pipe_stream).
+template <typename T, int NCH, int PMAX, int D>
 __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 {
     typedef typename Elem<T>::vec VT;
@@ -1178,11 +1197,11 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nvec = ld / V;
 
-    // LDS: (P+1) rows | nodes[-1 .. P] | reduction scratch
+    // LDS: (P+1) rows, or the 3 rotating row buffers | nodes[-1 .. P] | (16 spare bytes) | reduction scratch
     T *rows = reinterpret_cast<T *>(smem);
-    const size_t rows_bytes = (size_t)(A.P + 1) * ld * sizeof(T);
+    const size_t rows_bytes = (size_t)(D > 0 ? 3 : A.P + 1) * ld * sizeof(T);
     int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
-    Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4);
+    Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4 + (D > 0 ? 16 : 0));
 
     constexpr bool TABU = false;
     const T *mat = static_cast<const T *>(A.mat);
@@ -1199,16 +1218,22 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
     const Partial pq0 = part[min((int)threadIdx.x, (int)gridDim.x - 1)];   // issued before k_done is back: one trip less
     // the old records of the own b's depend on nothing either: in flight during the reduction
-    int qv[NCH][V], lv[NCH][V], rv[NCH][V];
-    AT dlv[NCH][V], drv[NCH][V];
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
+    // (up to 16 b's per thread; beyond that the registers are needed elsewhere: loaded chunk by chunk below)
+    constexpr bool HOIST = NCH * V <= 16;
+    constexpr int HC = HOIST ? NCH : 1;
+    int qv[HC][V], lv[HC][V], rv[HC][V];
+    AT dlv[HC][V], drv[HC][V];
+    auto load_old = [&](int c, int slot) __attribute__((always_inline)) {
         const int b0 = min((c * (int)blockDim.x + (int)threadIdx.x) * V, ld - V);
-        load_run<V>(pos_o + b0, qv[c]);
-        load_run<V>(nl_o + b0, lv[c]);
-        load_run<V>(nr_o + b0, rv[c]);
-        load_run<V>(dl_o + b0, dlv[c]);
-        load_run<V>(dr_o + b0, drv[c]);
+        load_run<V>(pos_o + b0, qv[slot]);
+        load_run<V>(nl_o + b0, lv[slot]);
+        load_run<V>(nr_o + b0, rv[slot]);
+        load_run<V>(dl_o + b0, dlv[slot]);
+        load_run<V>(dr_o + b0, drv[slot]);
+    };
+    if constexpr (HOIST) {
+#pragma unroll
+        for (int c = 0; c < NCH; c++) load_old(c, c);
     }
 
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
@@ -1291,15 +1316,18 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     for (int c = 0; c < NCH; c++) {
         const int ub0 = (c * BT + tid) * V;
         const bool mine = ub0 < n && ub0 / slice == (int)blockIdx.x;
+        constexpr int hc_dummy = 0;
+        const int hc = HOIST ? c : hc_dummy;
+        if constexpr (!HOIST) load_old(c, 0);
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int b = (c * BT + tid) * V + v;
-            int r = qv[c][v] - lo;
+            int r = qv[hc][v] - lo;
             if (r < 0) r += n;
             const bool inr = r < M;
-            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[c][v];
-            int l2 = inr ? rv[c][v] : lv[c][v], r2 = inr ? lv[c][v] : rv[c][v];
-            AT dl2 = inr ? drv[c][v] : dlv[c][v], dr2 = inr ? dlv[c][v] : drv[c][v];
+            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[hc][v];
+            int l2 = inr ? rv[hc][v] : lv[hc][v], r2 = inr ? lv[hc][v] : rv[hc][v];
+            AT dl2 = inr ? drv[hc][v] : dlv[hc][v], dr2 = inr ? dlv[hc][v] : drv[hc][v];
             if (move) {
                 if (b == x0) { r2 = x2; dr2 = wA; }
                 if (b == x3) { l2 = x1; dl2 = wB; }
@@ -1331,6 +1359,11 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     if (stamp && tid == 0) { stamp[0] = t_entry; stamp[5] = t_red; }
     STAMP(1);
 
+    Best q;
+    best_init<false>(q);
+    if constexpr (D > 0) {
+        pipe_stream<T, NCH, D, false>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, 0, 0, stamp);
+    } else {
     // every row of the run in flight at once
     VT R[PMAX + 1][NCH];
 #pragma unroll
@@ -1344,8 +1377,6 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;
-    Best q;
-    best_init<false>(q);
 
     auto step = [&](int s) __attribute__((always_inline)) {
         const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
@@ -1379,6 +1410,8 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
             const int s_end = min(cnt, r0 + RPC - 1);   // steps s with row s+1 <= r0+RPC-1
             for (; s < s_end; s++) step(s);
         }
+    }
+
     }
 
     STAMP(3);
@@ -1958,11 +1991,16 @@ static const void *res_kernel(int elem, int nch, bool tabu)
     return fn;
 }
 
-template <typename T, int NCH> static const void *fused_fn() { return (const void *)k_sweep_fused<T, NCH, 8>; }
-static const void *fused_kernel(int elem, int nch)
+template <typename T, int NCH, int D> static const void *fused_fn() { return (const void *)k_sweep_fused<T, NCH, 8, D>; }
+// kernel 3: resident rows (nch 1, 2); kernel 2: streamed rows, depth 2 (nch 1, 2, and 3 for uint16)
+static const void *fused_kernel(int elem, int nch, int kernel)
 {
     const void *fn = nullptr;
-    ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1>() : fused_fn<T, 2>());
+    if (kernel == 3) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 0>() : nch == 2 ? fused_fn<T, 2, 0>() : nullptr);
+    else if (kernel == 2) {
+        ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
+        if (nch == 3 && elem == TSPGPU_ELEM_U16) fn = fused_fn<u16, 3, 2>();
+    }
     return fn;
 }
 
@@ -2039,7 +2077,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     if (kernel == 0) {
         // uint16: resident whenever it fits.  int32 / f64: resident only while 9 rows leave room
         // for two workgroups per CU (small n, multi-start batches); else pipelined; else simple.
-        if (res_ok && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
+        // A single tour whose resident runs would not all be on the chip at once (more than two
+        // workgroups per CU's worth: a second, mostly empty round) streams instead.
+        const bool res_one_round = ntours > 1 || (n + res_P() - 1) / std::max(1, res_P()) <= 2 * ctx->cus;
+        if (res_ok && (res_one_round || !pipe_fits(BT, 64)) && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
         else kernel = pipe_fits(BT, 64) ? 2 : 1;
     }
     if (kernel == 3) {
@@ -2064,7 +2105,14 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             nch = inst;
             ctx->plan_D = pipe_depth(nch, ctx->opt_depth);
             plan_GP(3 * row + slack, BT, G, P, pipe_kernel(ctx->elem, nch, ctx->plan_D, false));
-            if (ctx->opt_wgs <= 0 && P < 8) { // each run fetches P+1 rows: keep the extra row under ~12 %
+            if (ctx->opt_wgs <= 0 && ntours == 1) {
+                // a whole number of workgroups per CU (an uneven last round costs a full one), the
+                // most that keeps runs of >= 8 edges (each run fetches P+1 rows: extra row <= 12 %)
+                int k = std::max(1, G / ctx->cus);
+                while (k > 1 && (n + ctx->cus * k - 1) / (ctx->cus * k) < 8) k--;
+                if ((n + ctx->cus * k - 1) / (ctx->cus * k) >= 8) { P = (n + ctx->cus * k - 1) / (ctx->cus * k); G = (n + P - 1) / P; }
+            }
+            if (ctx->opt_wgs <= 0 && P < 8) {
                 P = std::min(n, 8); G = (n + P - 1) / P;
             }
             while (!pipe_fits(BT, P) && G < MAX_WGS_PER_TOUR) { G *= 2; P = (n + G - 1) / G; G = (n + P - 1) / P; }
@@ -2082,10 +2130,8 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     if (n > 64 * 1024) return fail(ctx, E_EXHAUSTED, "n=%d exceeds the matrix-mode limit", n);
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
     // raise the dynamic-LDS cap of the kernels we are going to launch
-    if (kernel == 3) {
-        const void *ff = fused_kernel(ctx->elem, nch);
+    if (const void *ff = fused_kernel(ctx->elem, nch, kernel))
         HIP_TRY(hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
-    }
     for (int tabu = 0; tabu < 2; tabu++) {
         const void *fn = kernel == 3 ? res_kernel(ctx->elem, nch, tabu)
                        : kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
@@ -2186,7 +2232,8 @@ static int launch_fused(tspgpu_ctx *ctx, int slot0, int ntours, int parity)
     A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
     A.pts = ctx->d_pts; A.spts = nullptr; A.kind = ctx->kind;
     A.F = ctx->F; A.parity = parity; A.hist = ctx->hist;
-    const void *fn = fused_kernel(ctx->elem, ctx->plan_NCH);
+    const void *fn = fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel);
+    if (!fn) return fail(ctx, E_INTERNAL, "no one-launch-per-sweep instance for kernel %d, %d chunks", ctx->plan_kernel, ctx->plan_NCH);
     void *args[] = {&A};
     HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
     return E_OK;
@@ -2275,7 +2322,7 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
     // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
     // tour at once and the leaner sweep wins (measured 7.0e11 vs 5.0e11 evals/s at 64 tours).
-    if (!tabu && ctx->plan_kernel == 3 && ctx->symmetric &&
+    if (!tabu && ctx->symmetric && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel) &&
         (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
         return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
@@ -2531,7 +2578,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 8: return ctx->cus;
     case 9: return ctx->plan_D;
     case 10: return ctx->otf ? 1 : 0;
-    case 11: return (ctx->plan_kernel == 3 && ctx->symmetric && ctx->opt_fused) ? 1 : 0;
+    case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel)) ? 1 : 0;
     }
     return -1;
 }
