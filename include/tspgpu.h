@@ -126,6 +126,12 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k,
  * start (starts == NULL: 0..nstarts-1), first strictly-best kept. */
 int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts,
                   int *best_path, double *best_cost, int *best_start);
+/* The same under the reference's cooperative deadline (heuristics.c:43-49: checked before every
+ * start): starts are processed in ascending batches sized to the time left (time_left_s < 0:
+ * no limit); returns DEADLINE_EXCEEDED (4) with the best of the *done_starts processed so far
+ * (best_start = -1 if none). */
+int tspgpu_nn_all_timed(tspgpu_ctx *ctx, const int *starts, int nstarts, double time_left_s,
+                        int *best_path, double *best_cost, int *best_start, int *done_starts);
 
 /* h_greedy_2opt (src/algorithms/heuristics.c:74-116): NN + 2-opt from every
  * listed start, all on the device; the winner is the lowest cost, ties to the

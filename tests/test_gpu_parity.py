@@ -219,6 +219,40 @@ def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
     assert O.valid_tour(succ)
 
 
+def test_nn_all_under_deadline(eng, T, O, instances):
+    """h_Greedy_iterative's cooperative deadline: the starts done form a prefix, the result is the
+    first strictly best of that prefix"""
+    xy, c = setup(eng, T, O, instances, "pr1002", 0)
+    n = len(xy)
+    full = eng.nn_all()
+    path, cost, start, done, rc = eng.nn_all_timed(None, -1.0)
+    assert rc == 0 and done == n and (cost, start) == (full[1], full[2]) and np.array_equal(path, full[0])
+    path, cost, start, done, rc = eng.nn_all_timed(None, 0.0)
+    assert rc == T.DEADLINE_EXCEEDED and done == 0 and start == -1
+    path, cost, start, done, rc = eng.nn_all_timed(None, 0.004)
+    assert 0 < done <= n and rc in (0, T.DEADLINE_EXCEEDED)
+    costs = [O.nn_tour(c, s)[1] for s in range(done)]
+    assert cost == min(costs) and start == int(np.argmin(costs))
+    want, _ = O.nn_tour(c, start)
+    assert np.array_equal(path, want)
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 8, 9, 15, 17, 33, 63, 65, 127, 129, 511, 513, 517])
+@pytest.mark.parametrize("elem", [0, 1])
+def test_tiny_and_ragged_sizes(eng, T, O, instances, n, elem, fused):
+    """sizes around the wave / block / vector boundaries: NN, every sweep and the final tour
+    against the oracle (n = 4 is the smallest instance with a valid 2-opt pair)"""
+    xy, c = instances(f"n{n}_s{n + 11}")
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, 0)
+    g, gcost = eng.nn_tour(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    want_sweeps, want_cost = O.two_opt(c, succ)
+    got_cost, got_sweeps, rc = eng.two_opt(g)
+    assert rc == 0 and (got_cost, got_sweeps) == (want_cost, want_sweeps) and np.array_equal(g, succ)
+
+
 def test_n16384_first_sweeps(eng, T, O, fused):
     """the large size of the throughput table (uint16 rows of 32 KB: pipelined kernel, two chunks
     per thread): NN(0) and the first sweeps against the oracle, move by move"""

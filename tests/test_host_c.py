@@ -166,3 +166,18 @@ def test_binary_matrix_free_pla85900():
     # and on a small instance the matrix-free binary equals the matrix binary
     rc, out, err = run_q("-f", os.path.join(DATA, "kroA100.tsp"), "-alg", "2OPT_GREEDY", env={"TSP_MATRIX_FREE": "1"})
     assert rc == 0 and out == "Cost: 21360.00", err
+
+
+@pytest.mark.gpu
+def test_binary_vns_pla85900_honours_deadline():
+    """config 5 as BASELINE names it (VNS over the matrix-free engine) under the reference's
+    cooperative time limit: All-NN is cut at the deadline (heuristics.c:43-49 checks before every
+    start), the result is a valid tour no worse than NN(0), and the process ends soon after -t"""
+    import json, time
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))["pla85900"]
+    t0 = time.time()
+    rc, out, err = run_q("-f", os.path.join(DATA, "pla85900.tsp"), "-alg", "VNS", "-k", "1", "-t", "12", env={"TSP_ALLOW_EXT": "1"})
+    dt = time.time() - t0
+    assert rc == 0 and out.startswith("Cost: "), err
+    assert float(out.split(":")[1]) <= g["nn_cost"]
+    assert dt < 60, dt

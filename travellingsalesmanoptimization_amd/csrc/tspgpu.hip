@@ -2902,18 +2902,26 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
     return E_OK;
 }
 
-int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts, int *best_path, double *best_cost, int *best_start)
+int tspgpu_nn_all_timed(tspgpu_ctx *ctx, const int *starts, int nstarts, double time_left_s, int *best_path, double *best_cost,
+                        int *best_start, int *done_starts)
 {
     if (!ctx || !best_path || !best_cost || !best_start || nstarts <= 0) return fail(ctx, E_INVALID, "bad argument");
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
-    const int n = ctx->n;
-    const int chunk = std::min(nstarts, ctx->opt_max_tours);
-    if ((rc = ensure_tours(ctx, chunk))) return rc;
+    const double t0 = now_s();
+    const double t_end = time_left_s >= 0 ? t0 + time_left_s : -1;
+    const int cap = std::min(nstarts, ctx->opt_max_tours);
+    if ((rc = ensure_tours(ctx, cap))) return rc;
     double best = DBL_MAX; int arg = -1;
-    std::vector<int> hs(chunk);
-    for (int base = 0; base < nstarts; base += chunk) {
+    std::vector<int> hs(cap);
+    // under a deadline: first one start per CU, then batches of about a quarter of the time left
+    // (at most ~0.5 s) at the rate measured so far; the reference checks before every start
+    int chunk = t_end >= 0 ? std::min(cap, std::max(1, ctx->cus)) : cap;
+    int base = 0;
+    bool late = false;
+    while (base < nstarts) {
+        if (t_end >= 0 && now_s() >= t_end) { late = true; break; }
         const int m = std::min(chunk, nstarts - base);
         for (int i = 0; i < m; i++) hs[i] = starts ? starts[base + i] : base + i;
         if ((rc = launch_nn(ctx, 0, hs.data(), m))) return rc;
@@ -2926,9 +2934,21 @@ int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts, int *best_pat
             if ((rc = init_slots(ctx, win, 1, -1))) return rc;
             if ((rc = store_path(ctx, win, best_path, nullptr, nullptr))) return rc;
         }
+        base += m;
+        if (t_end >= 0) {
+            const double now = now_s(), rate = base / std::max(now - t0, 1e-6);     // starts per second
+            const double budget = std::min(0.5, std::max(0.0, t_end - now) / 4);
+            chunk = (int)std::min<double>(cap, std::max<double>(std::min(cap, ctx->cus), rate * budget));
+        }
     }
     *best_cost = best; *best_start = arg;
-    return E_OK;
+    if (done_starts) *done_starts = base;
+    return late ? E_DEADLINE : E_OK;
+}
+
+int tspgpu_nn_all(tspgpu_ctx *ctx, const int *starts, int nstarts, int *best_path, double *best_cost, int *best_start)
+{
+    return tspgpu_nn_all_timed(ctx, starts, nstarts, -1.0, best_path, best_cost, best_start, nullptr);
 }
 
 int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, double time_left_s, int *best_path,

@@ -128,6 +128,15 @@ class Engine:
         self._ck(self.L.tspgpu_nn_all(self.ctx, p, m, best, C.byref(c), C.byref(s)))
         return best, c.value, s.value
 
+    def nn_all_timed(self, starts=None, time_left_s=-1.0):
+        """h_Greedy_iterative under its deadline -> (best_path, best_cost, best_start, done_starts, rc)."""
+        p, m, keep = self._starts(starts, self.n)
+        best = np.empty(self.n, dtype=np.int32)
+        c, s, d = C.c_double(), C.c_int(), C.c_int()
+        rc = self._ck(self.L.tspgpu_nn_all_timed(self.ctx, p, m, float(time_left_s), best, C.byref(c), C.byref(s), C.byref(d)),
+                      ok=(T_OK, DEADLINE_EXCEEDED))
+        return best, c.value, s.value, d.value, rc
+
     def multistart_nn_2opt(self, starts=None, time_left_s=-1.0, want_last=False):
         """h_greedy_2opt (heuristics.c:74-116) -> dict."""
         p, m, keep = self._starts(starts, self.n)

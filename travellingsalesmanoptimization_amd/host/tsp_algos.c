@@ -151,11 +151,11 @@ ERROR_CODE h_Greedy_iterative(void)
     if (!g) return UNAVAILABLE;
     tsp_solution s;
     tsp_init_solution(tsp_inst.nnodes, &s);
-    int start = -1;
-    int rc = tspgpu_nn_all(g, NULL, tsp_inst.nnodes, s.path, &s.cost, &start);
+    int start = -1, done = 0;
+    int rc = tspgpu_nn_all_timed(g, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &done);
     ERROR_CODE e = from_rc(rc);
-    if (rc) log_error("tspgpu_nn_all: %s", tspgpu_last_error(g));
-    else if (s.cost < tsp_inst.best_solution.cost) {
+    if (rc && rc != DEADLINE_EXCEEDED) log_error("tspgpu_nn_all: %s", tspgpu_last_error(g));
+    else if (start >= 0 && s.cost < tsp_inst.best_solution.cost) {
         log_info("found new best, node %d", start);
         tsp_inst.starting_node = start;
         ERROR_CODE u = tsp_update_best_solution(&s);
