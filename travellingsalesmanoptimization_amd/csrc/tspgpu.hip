@@ -290,6 +290,12 @@ struct Fused {               // ping-pong state of the one-launch-per-sweep path
     double *cost[2];                        // [cap]
     Partial *partial[2];                    // [cap][pstride]
     int *cur;                               // [cap] parity holding the result once `done`
+    // uint16 cells: instead of partials every workgroup atomic-mins ONE packed 64-bit key per tour
+    // (delta:19 | a:16 | b:16 | workgroup:13; three slots in rotation: read / written / reset) and
+    // the workgroups leave the geometry of their best move in a record the next launch reads
+    // with one scalar load: {cell a, cell b, a, succ a, b, succ b, c[a][b], c[sa][sb]}
+    long long *bestkey;                     // [cap][4]
+    int *payload[2];                        // [cap][pstride][8]
 };
 
 template <typename T>
@@ -1143,6 +1149,7 @@ __global__ void __launch_bounds__(256) k_fused_begin(Tours S, Fused F, int n, in
     if (p == 0) {
         F.dir[1][t] = S.dir[t]; F.k[1][t] = 0; F.cost[1][t] = S.cost[t]; F.stop[1][t] = 0; F.stop[0][t] = 0;
         F.cur[t] = 1;
+        F.bestkey[t * 4 + 0] = 0; F.bestkey[t * 4 + 1] = 0; F.bestkey[t * 4 + 2] = 0;
     }
 }
 
@@ -1172,6 +1179,7 @@ __global__ void __launch_bounds__(256) k_fused_end(Tours S, Fused F, int n, int 
 // no LDS staging, no vector-memory queueing.
 typedef __attribute__((address_space(4))) const int c_i32;
 typedef __attribute__((address_space(4))) const double c_f64;
+typedef __attribute__((address_space(4))) const long long c_i64;
 template <typename T>
 __device__ __forceinline__ typename Elem<T>::acc scalar_cell(const T *mat, size_t idx)
 {
@@ -1215,8 +1223,15 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int dir_o = ((c_i32 *)A.F.dir[rd])[t];
     const int stop_o = ((c_i32 *)A.F.stop[rd])[t];
     const int cap = A.S.cap_sweeps[t];
+    // PAY (uint16 cells): the previous launch's result is one atomically minimised key + the
+    // winner's geometry record; else: per-workgroup partials, reduced here by every workgroup
+    constexpr bool PAY = sizeof(T) == 2;
     const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
-    const Partial pq0 = part[min((int)threadIdx.x, (int)gridDim.x - 1)];   // issued before k_done is back: one trip less
+    Partial pq0;
+    pq0.d = 0.0; pq0.key = 0;
+    if constexpr (!PAY) pq0 = part[min((int)threadIdx.x, (int)gridDim.x - 1)];   // issued before k_done is back: one trip less
+    const long long K0 = PAY ? ((c_i64 *)A.F.bestkey)[t * 4 + 0] : 0, K1 = PAY ? ((c_i64 *)A.F.bestkey)[t * 4 + 1] : 0,
+                    K2 = PAY ? ((c_i64 *)A.F.bestkey)[t * 4 + 2] : 0;      // all three slots: no trip behind k_done
     // the old records of the own b's depend on nothing either: in flight during the reduction
     // (up to 16 b's per thread; beyond that the registers are needed elsewhere: loaded chunk by chunk below)
     constexpr bool HOIST = NCH * V <= 16;
@@ -1243,7 +1258,17 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // ---- the move found by the previous launch (every workgroup reduces the same partials)
     double md = 0.0;
     u64 mkey = 0;
-    if (k_done > 0) {
+    int pwg = 0;
+    if constexpr (PAY) {
+        if (k_done > 0) {
+            const int sl = (k_done + 2) % 3;
+            const long long K = sl == 0 ? K0 : sl == 1 ? K1 : K2;
+            md = (double)(int)(K >> 45);
+            mkey = ((u64)(unsigned)((K >> 29) & 0xffff) << 32) | (unsigned)((K >> 13) & 0xffff);
+            pwg = (int)(K & 0x1fff);
+        }
+        if (blockIdx.x == 0 && tid == 0) A.F.bestkey[t * 4 + (k_done + 1) % 3] = 0;   // the slot the NEXT launch minimises into
+    } else if (k_done > 0) {
         if (tid < (int)gridDim.x) { md = pq0.d; mkey = pq0.key; }
         for (int g = tid + BT; g < (int)gridDim.x; g += BT) {     // more workgroups than threads: not with the default plans
             const Partial q = part[g];
@@ -1275,7 +1300,15 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     int x0 = -1, x1 = -1, x2 = -1, x3 = -1;
     AT wA = 0, wB = 0;
     if (move) {
-        const int i = pos_c[ma], j = pos_c[mb];
+        int i, j, sma = 0, smb = 0;
+        AT cab = 0, css = 0;
+        if constexpr (PAY) {
+            c_i32 *pay = (c_i32 *)(A.F.payload[rd] + ((size_t)t * A.S.pstride + pwg) * 8);
+            const bool sw = pay[2] > pay[4];            // the record is in the winner's orientation (a = its run node)
+            i = sw ? pay[1] : pay[0]; j = sw ? pay[0] : pay[1];
+            sma = sw ? pay[5] : pay[3]; smb = sw ? pay[3] : pay[5];
+            cab = pay[6]; css = pay[7];
+        } else { i = pos_c[ma]; j = pos_c[mb]; }
         int L = (j - i) * dir_o;
         if (L < 0) L += n;
         const bool other = n - L < L;
@@ -1283,10 +1316,18 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         const int first = other ? wrap(j + dir_o, n) : wrap(i + dir_o, n);
         lo = dir_o > 0 ? first : wrap(first - (M - 1), n);
         if (other) ndir = -dir_o;
-        x0 = ord_c[wrap(lo - 1, n)]; x1 = ord_c[lo];
-        x2 = ord_c[wrap(lo + M - 1, n)]; x3 = ord_c[wrap(lo + M, n)];
-        wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
-        wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
+        if constexpr (PAY) {
+            // the four nodes around the reversed range and the two new edge costs follow from the
+            // record: no further memory trip
+            if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
+            else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
+            wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
+        } else {
+            x0 = ord_c[wrap(lo - 1, n)]; x1 = ord_c[lo];
+            x2 = ord_c[wrap(lo + M - 1, n)]; x3 = ord_c[wrap(lo + M, n)];
+            wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
+            wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
+        }
     }
     auto new_cell = [&](int p) __attribute__((always_inline)) {   // old cell holding what cell p holds after the move
         int r = p - lo;
@@ -1311,6 +1352,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // beyond scalars.  The workgroup that owns a slice of b's also writes their new records.
     BState<T, NCH> B;
     B.skm = 0;
+    unsigned qpk[PAY ? NCH : 1][PAY ? V / 2 : 1];      // new cell of every own b, 16-bit pairs (for the record)
     const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
@@ -1342,6 +1384,9 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
             const int sb = b < n ? (ndir > 0 ? r2 : l2) : 0;
             const AT dn = ndir > 0 ? dr2 : dl2;
             bstate_set<T, NCH>(B, c, v, sb, dn, b >= n, false);
+            if constexpr (PAY) {
+                if (v & 1) qpk[c][v / 2] |= (unsigned)qn << 16; else qpk[c][v / 2] = (unsigned)qn & 0xffffu;
+            }
         }
     }
     if (blockIdx.x == 0 && tid == 0) {                   // per-tour scalars of the new state
@@ -1415,11 +1460,52 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
 
     STAMP(3);
-    double d;
-    u64 key;
-    best_finish<T, false>(q, d, key);
+    double d_own;
+    u64 key_own;
+    best_finish<T, false>(q, d_own, key_own);
+    double d = d_own;
+    u64 key = key_own;
     block_argmin(d, key, scratch);
-    if (tid == 0) {
+    if constexpr (PAY) {
+        // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated
+        // once): it leaves the record and takes part in the tour-wide atomic min
+        if (key != 0 && key_own == key && d_own == d) {
+            const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
+            int own = -1, idx = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
+                const int b0c = (c * BT + tid) * V;
+                if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
+            }
+            if (own < 0) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const int b0c = (c * BT + tid) * V;
+                    if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
+                }
+            }
+            const int other = own == lb ? la : lb;
+            unsigned pk = 0, qq = 0;
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int v = 0; v < V; v++)
+                    if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; qq = (v & 1) ? qpk[c][v / 2] >> 16 : qpk[c][v / 2] & 0xffffu; }
+            const int sb = (int)(pk & 0xffffu) / (int)sizeof(T);
+            int sidx = 0;
+            for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
+            const int sa = nodes[sidx + 1];
+            const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
+            int w1, w2;
+            if constexpr (D == 0) { w1 = (int)rows[(size_t)sidx * ld + own]; w2 = (int)rows[(size_t)(sidx + 1) * ld + sb]; }
+            else { w1 = (int)mat[(size_t)other * ld + own]; w2 = (int)mat[(size_t)sa * ld + sb]; }
+            int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * 8;
+            *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
+            *reinterpret_cast<v4i32 *>(pay + 4) = v4i32{own, sb, w1, w2};
+            const long long K = ((long long)(int)d << 45) | ((long long)la << 29) | ((long long)lb << 13) | (long long)blockIdx.x;
+            atomicMin(A.F.bestkey + t * 4 + k_done % 3, K);
+        }
+    } else if (tid == 0) {
         Partial o; o.d = d; o.key = key;
         A.F.partial[wr][(size_t)t * A.S.pstride + blockIdx.x] = o;
     }
@@ -1869,6 +1955,8 @@ static void free_tours(tspgpu_ctx *ctx)
             for (void *q : fp) if (q) hipFree(q);
         }
         if (F.cur) hipFree(F.cur);
+        if (F.bestkey) hipFree(F.bestkey);
+        for (int p = 0; p < 2; p++) if (F.payload[p]) hipFree(F.payload[p]);
         memset(&F, 0, sizeof F);
         ctx->fcap = 0;
     }
@@ -2216,6 +2304,8 @@ static int ensure_fused(tspgpu_ctx *ctx)
         HIP_TRY(hipMemsetAsync(F.dr[p], 0, (T * N + slack) * 8, ctx->stream));
     }
     HIP_TRY(hipMalloc(&F.cur, T * 4));
+    HIP_TRY(hipMalloc(&F.bestkey, T * 4 * 8));
+    for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&F.payload[p], T * (size_t)ctx->S.pstride * 8 * 4));
     ctx->fcap = ctx->tcap;
     return E_OK;
 }
