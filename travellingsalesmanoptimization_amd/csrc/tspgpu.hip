@@ -373,16 +373,6 @@ __global__ void __launch_bounds__(1024) k_tour_init(Tours S, const T *__restrict
     }
 }
 
-// successor array for the host (tsp_solution.path): succ[ord[p]] = ord[p + dir]
-__global__ void __launch_bounds__(256) k_export_succ(Tours S, int n, int slot0)
-{
-    const int t = slot0 + blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const int *ord = S.ord + (size_t)t * n;
-    S.succ[(size_t)t * n + ord[p]] = ord[wrap(p + S.dir[t], n)];
-}
-
 // ---------------------------------------------------------------------------
 // K6: nearest-neighbour tour, one workgroup per start.  Thread tid owns nodes
 // tid, tid+BT, ... (coalesced row reads) and keeps their visited bits in a
