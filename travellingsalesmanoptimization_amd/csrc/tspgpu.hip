@@ -2070,14 +2070,15 @@ static const void *res_kernel(int elem, int nch, bool tabu)
 }
 
 template <typename T, int NCH, int D> static const void *fused_fn() { return (const void *)k_sweep_fused<T, NCH, 8, D>; }
-// kernel 3: resident rows (nch 1, 2); kernel 2: streamed rows, depth 2 (nch 1, 2, and 3 for uint16)
+// kernel 3: resident rows (nch 1, 2); kernel 2: streamed rows, depth 2 (nch 1, 2)
 static const void *fused_kernel(int elem, int nch, int kernel)
 {
     const void *fn = nullptr;
     if (kernel == 3) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 0>() : nch == 2 ? fused_fn<T, 2, 0>() : nullptr);
     else if (kernel == 2) {
+        // (three uint16 chunks per thread, n > 16 384: the fused prologue no longer fits the register
+        // budget next to the per-b state -- measured 1.7x slower than sweep + apply on d18512)
         ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
-        if (nch == 3 && elem == TSPGPU_ELEM_U16) fn = fused_fn<u16, 3, 2>();
     }
     return fn;
 }
