@@ -433,6 +433,96 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
 }
 
 // ---------------------------------------------------------------------------
+// K6, matrix mode: the same tour with 16-byte row reads.  A thread owns V consecutive nodes
+// per chunk (chunk c: nodes (c BT + tid) V ...), visited bits in a 128-bit register mask
+// (n <= 16 BT V).  Integer cells: the candidate is ONE unsigned 64-bit key (weight << 32 |
+// index), so the (weight, index) argmin -- ties to the lowest index, the strict < of
+// heuristics.c:258 -- is a plain min through the wave shuffles and the LDS round.  One memory
+// trip, one barrier per step: 2-3x the step rate of the strided kernel above, which stays for
+// the matrix-free mode.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(1024) k_nn_vec(Tours S, const T *__restrict__ mat, int n, int ld, int slot0,
+                                                 const int *__restrict__ starts)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    constexpr bool INT = !std::is_same<T, double>::value;
+    __shared__ Partial red[2][16];
+    const int t = slot0 + blockIdx.x;
+    const int start = starts[blockIdx.x];
+    int *ord = S.ord + (size_t)t * n;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nw = (BT + 63) >> 6;
+    const int nvec = ld / V;
+    const int nch = (nvec + BT - 1) / BT;          // <= 16 (host)
+    u64 seen = 0, seen_hi = 0;                     // bit c*V+v <-> node (c*BT + tid)*V + v
+    auto mark = [&](int node) __attribute__((always_inline)) {
+        const int vi = node / V, c = vi / BT;
+        if (vi - c * BT == tid) { const int k = c * V + node % V; if (k < 64) seen |= 1ull << k; else seen_hi |= 1ull << (k - 64); }
+    };
+    mark(start);
+    int cur = start;
+    double total = 0;
+    if (tid == 0) ord[0] = start;
+    int step = 1;
+    for (; step < n; step++) {
+        const VT *row = reinterpret_cast<const VT *>(mat + (size_t)cur * ld);
+        double lo = DBL_MAX;
+        u64 arg = KEY_NONE;      // INT: the packed key itself; doubles: the index
+        for (int c = 0; c < nch; c++) {
+            const int vi = c * BT + tid;
+            if (vi >= nvec) break;
+            const VT x = row[vi];
+            const u64 bits = (c * V < 64 ? seen >> (c * V) : seen_hi >> (c * V - 64));
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const int i = vi * V + v;
+                const bool free_ = i < n && !((bits >> v) & 1);
+                if constexpr (INT) {
+                    const unsigned raw = (unsigned)x[v];
+                    const bool conn = sizeof(T) == 2 ? raw != 0xFFFFu : (int)raw != -1;   // NOT_CONNECTED, utils.h:35
+                    const u64 key = ((u64)raw << 32) | (unsigned)i;
+                    arg = (free_ && conn && key < arg) ? key : arg;
+                } else {
+                    const double w = x[v];
+                    if (free_ && w != -1.0 && w < lo) { lo = w; arg = (u64)i; }
+                }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            if constexpr (INT) {
+                const u64 oa = __shfl_xor(arg, off);
+                arg = oa < arg ? oa : arg;
+            } else {
+                double od = __shfl_xor(lo, off);
+                u64 oa = __shfl_xor(arg, off);
+                if (key_better(od, oa, lo, arg)) { lo = od; arg = oa; }
+            }
+        }
+        Partial *r = red[step & 1];
+        if ((tid & 63) == 0) { r[tid >> 6].d = lo; r[tid >> 6].key = arg; }
+        __syncthreads();
+        lo = r[0].d; arg = r[0].key;
+        for (int w = 1; w < nw; w++) {
+            if constexpr (INT) arg = r[w].key < arg ? r[w].key : arg;
+            else if (key_better(r[w].d, r[w].key, lo, arg)) { lo = r[w].d; arg = r[w].key; }
+        }
+        if (arg == KEY_NONE) break; // nothing reachable: heuristics.c:268-272 closes the path here
+        const int nxt = (int)(arg & 0xffffffffu);
+        if constexpr (INT) lo = (double)(unsigned)(arg >> 32);
+        mark(nxt);
+        if (tid == 0) { ord[step] = nxt; total += lo; }
+        cur = nxt;
+    }
+    if (tid == 0) {
+        total += Elem<T>::widen(mat[(size_t)cur * ld + start]); // heuristics.c:281
+        S.cost[t] = total;
+        S.status[t] = (step == n) ? 0 : 1; // 1: tour left incomplete
+    }
+}
+
+// ---------------------------------------------------------------------------
 // sweep arguments
 // ---------------------------------------------------------------------------
 struct SweepArgs {
@@ -2537,6 +2627,17 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
         if (h_starts[i] < 0 || h_starts[i] >= n) return fail(ctx, E_UNAVAILABLE, "starting node %d not in [0,%d)", h_starts[i], n);
     HIP_TRY(hipMemcpyAsync(ctx->d_starts, h_starts, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->d_mat && !ctx->otf) {
+        // matrix mode: vector row reads, one or two 16-byte vectors per thread where n allows
+        const int V = 16 / (int)elem_size(ctx->elem), nvec = ctx->ld / V;
+        int BT = std::min(1024, std::max(64, (nvec + 63) & ~63));
+        if ((nvec + BT - 1) / BT <= 16) {
+            ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn_vec<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
+                                                         (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts));
+            HIP_TRY(hipGetLastError());
+            return E_OK;
+        }
+    }
     int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
     while ((long)BT * 128 < n && BT < 1024) BT *= 2; // register visited mask: n <= 128*BT
     if ((long)BT * 128 < n) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 131072");
