@@ -665,10 +665,11 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
 // b > a.  So a wave is either wholly in, wholly out, or the one wave holding a's block -- no
 // wave straddles a range boundary, and the b's of the two neighbours of a need no mask at all:
 // their delta is exactly 0 (c[a][pa] + c[sa][a] - (c[a][sa] + c[pa][a]); IEEE addition
-// commutes), never an improvement.  Otherwise (caller matrix not symmetric: b > a; tabu: every
-// admissible pair counts, non-improving ones too): the cyclic index range [lo, lo+len-1],
-// masked per lane wherever a wave straddles its ends or holds one of the three nodes around a
-// (refinment.c:55: b == a, b == succ a, succ b == a).
+// commutes), never an improvement.  Tabu (every admissible pair counts, a zero delta can be the
+// best one) keeps the blocks and masks the two neighbours per lane in the waves that hold them.
+// Caller matrix not symmetric: the reference's own orientation b > a as the cyclic index range
+// [lo, lo+len-1], masked per lane wherever a wave straddles its ends or holds one of the three
+// nodes around a (refinment.c:55: b == a, b == succ a, succ b == a).
 //
 // Argmin.  The reference keeps the first strictly smaller delta in (a asc, b asc) order, i.e.
 // it minimises (delta, min(a,b), max(a,b)).  Integer deltas (n < 65536): ONE signed 64-bit word,
@@ -715,6 +716,7 @@ __device__ __forceinline__ void best_init(Best &q)
     q.a = 0; q.b = 0; q.have = false;                                           // (0,0): "no move"; cannot win a tie
 }
 
+constexpr int TABU_NODE = 1 << 30, NODE_MASK = TABU_NODE - 1;   // nodes[] entries of the tabu kernels carry the node's tabu bit
 constexpr int MASKED32 = 1 << 27;   // masked pair on the 32-bit key path: (x << 3) must not overflow
 
 // bA: LDS row of a; bS: LDS row of succ a (ldsS: its LDS byte address).
@@ -723,7 +725,6 @@ template <typename T, int NCH, bool TABU, bool BLOCKS>
 __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, const T *bA, const unsigned char *bS, unsigned ldsS,
                                               int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric)
 {
-    static_assert(!(BLOCKS && TABU), "block ownership is for plain 2-opt");
     typedef typename Elem<T>::vec VT;
     typedef typename Elem<T>::acc AT;
     constexpr int V = Elem<T>::V;
@@ -747,7 +748,9 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
             if (d < 0) d += NB;
             self = d == 0;
             if (!self && !(2 * d < NB || (2 * d == NB && blka < blkb))) continue;   // the other orientation's
-            clean = !self && (!PKS || w0 + 64 * V <= n);   // packed state has no poison for pad lanes
+            // tabu: the two neighbours of a are real exclusions (a zero delta can be the best admissible one)
+            const bool hit = TABU && ((unsigned)(am - w0) < (unsigned)(64 * V) || (unsigned)(sa - w0) < (unsigned)(64 * V));
+            clean = !self && !hit && (!PKS || w0 + 64 * V <= n);   // packed state has no poison for pad lanes
         } else {
             int t0 = w0 - lo;
             if (t0 < 0) t0 += n;
@@ -761,7 +764,7 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
         const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
         auto valid = [&](int b) __attribute__((always_inline)) {
             asm volatile("" : "+v"(b));     // b < n is step-invariant: hoisted, it costs an SGPR pair per b
-            if (blocks) return ((b > a) | !self) & (b < n);
+            if (blocks) return ((b > a) | !self) & (b < n) & (!TABU | ((b != am) & (b != sa)));
             int tt = b - lo;
             tt += (tt >> 31) & n;
             return ((unsigned)tt < (unsigned)len) & (b != am) & (b != a) & (b != sa) & (b < n);
@@ -865,8 +868,10 @@ template <typename T, int NCH, bool TABU>
 __device__ __forceinline__ void sweep_step(Best &q, const BState<T, NCH> &B, const T *bA, const unsigned char *bS, unsigned ldsS,
                                            int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric)
 {
-    if constexpr (TABU) sweep_step_as<T, NCH, TABU, false>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, symmetric);
-    else if (symmetric) sweep_step_as<T, NCH, false, true>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true);
+    if constexpr (TABU) {
+        if (symmetric) sweep_step_as<T, NCH, true, true>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true);
+        else sweep_step_as<T, NCH, true, false>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, false);
+    } else if (symmetric) sweep_step_as<T, NCH, false, true>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true);
     else sweep_step_as<T, NCH, false, false>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, false);
 }
 
@@ -925,7 +930,7 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
         // the same bytes).  Past the end of the run (r > cnt) every lane re-reads one hot
         // vector instead: the number of loads in flight is then the same on every path,
         // which lets hipcc place exact counted vmcnt waits in front of the LDS writes.
-        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
+        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)(nodes[min(r, cnt)] & NODE_MASK) * ld);
         const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
 #pragma unroll
         for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
@@ -948,15 +953,16 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
 
     auto step = [&](int s, VT(&Rs)[NCH]) __attribute__((always_inline)) {
-        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);                 // wave-uniform: keep it scalar
-        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
-        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int a_raw = __builtin_amdgcn_readfirstlane(nodes[s]), sa_raw = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int a = a_raw & NODE_MASK;                                        // wave-uniform: keep it scalar
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]) & NODE_MASK;
+        const int sa = sa_raw & NODE_MASK;
         const T *bA = buf + (size_t)(s % 3) * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)((s + 1) % 3) * ld);
         const unsigned ldsS = lds0 + (unsigned)(((s + 1) % 3) * ld) * (unsigned)sizeof(T);
         if (stamp && s == 10 && (tid & 63) == 0) stamp[32 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 entered
         bool live = A.ablate != 1;
-        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        if constexpr (TABU) live = live && !((a_raw | sa_raw) & TABU_NODE);
         if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
         if (stamp && tid == 0 && s < 12) stamp[8 + 2 * s] = wall_clock64();      // compute done
         if (stamp && s == 10 && (tid & 63) == 0) stamp[48 + (tid >> 6)] = wall_clock64();   // per-wave: step 10 evaluated
@@ -1014,7 +1020,13 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     const int cnt = min(A.P, n - p0);
     // (host guarantees cnt >= 1 for every launched workgroup)
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
-    for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+    // (tabu: bit 30 marks a tabu node, so that the steps need no global read for it)
+    for (int i = tid - 1; i <= cnt; i += BT) {
+        const int v = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+        int flag = 0;
+        if constexpr (TABU) flag = is_tabu(A.tabu_list, v, iter, tenure) ? TABU_NODE : 0;
+        nodes[i] = v | flag;
+    }
 
     // per-thread state of the owned b's from the node-indexed view (coalesced 16-byte loads)
     BState<T, NCH> B;
@@ -1102,7 +1114,13 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     const int p0 = blockIdx.x * A.P;
     const int cnt = min(A.P, n - p0);
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
-    for (int i = tid - 1; i <= cnt; i += BT) nodes[i] = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+    // (tabu: bit 30 marks a tabu node, so that the steps need no global read for it)
+    for (int i = tid - 1; i <= cnt; i += BT) {
+        const int v = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+        int flag = 0;
+        if constexpr (TABU) flag = is_tabu(A.tabu_list, v, iter, tenure) ? TABU_NODE : 0;
+        nodes[i] = v | flag;
+    }
 
     // per-thread state of the owned b's: coalesced loads of the node-indexed view.  Issued
     // BEFORE the matrix rows: vector loads return in order, so anything younger than the rows
@@ -1138,7 +1156,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
 #pragma unroll
     for (int r = 0; r <= PMAX; r++) {
         if (r <= cnt && A.ablate != 2) {
-            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[r] * ld);
+            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)(nodes[r] & NODE_MASK) * ld);
 #pragma unroll
             for (int c = 0; c < NCH; c++) R[r][c] = src[min(c * BT + tid, nvec - 1)];
         }
@@ -1149,15 +1167,16 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     best_init<TABU>(q);
 
     auto step = [&](int s) __attribute__((always_inline)) {
-        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
-        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
-        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int a_raw = __builtin_amdgcn_readfirstlane(nodes[s]), sa_raw = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int a = a_raw & NODE_MASK;
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]) & NODE_MASK;
+        const int sa = sa_raw & NODE_MASK;
         const T *bA = rows + (size_t)s * ld;
         const unsigned char *bS = reinterpret_cast<const unsigned char *>(rows + (size_t)(s + 1) * ld);
         const unsigned ldsS = lds0 + (unsigned)((s + 1) * ld) * (unsigned)sizeof(T);
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         bool live = A.ablate != 1;
-        if constexpr (TABU) live = live && !(is_tabu(A.tabu_list, a, iter, tenure) || is_tabu(A.tabu_list, sa, iter, tenure));
+        if constexpr (TABU) live = live && !((a_raw | sa_raw) & TABU_NODE);
         if (live) sweep_step<T, NCH, TABU>(q, B, bA, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, A.symmetric != 0);
     };
 
