@@ -6,13 +6,18 @@
 //
 // What runs here, and the reference loop each kernel takes over (file:line in
 // the reference checkout):
-//   k_build_costs   src/tsp.c:616-633              n x n rounded-Euclidean matrix
-//   k_nn            src/algorithms/heuristics.c:216-288   nearest-neighbour tour
+//   k_build_costs   src/tsp.c:616-633              n x n rounded-Euclidean matrix (uint16 / int32 / f64 cells)
+//   k_nn_vec, k_nn  src/algorithms/heuristics.c:216-288   nearest-neighbour tour (matrix / matrix-free)
 //   k_tour_init     src/algorithms/refinment.c:6-9,43-46  cost recompute, prev/pos
-//   k_sweep_*       src/algorithms/refinment.c:49-69      full pair scan, argmin
-//                   src/algorithms/metaheuristic.c:198-222 (TABU variant)
-//   k_apply         src/algorithms/refinment.c:74-86,95-114  apply best move
+//   k_sweep_fused   src/algorithms/refinment.c:49-114     ONE launch per sweep: apply the previous
+//                                                         move + full pair scan (plain 2-opt)
+//   k_sweep_res / k_sweep_pipe / k_sweep_simple / k_sweep_otf
+//                   src/algorithms/refinment.c:49-69      full pair scan, argmin (rows resident in
+//                   src/algorithms/metaheuristic.c:198-222  LDS / streamed / one row / matrix-free);
+//                                                         TABU variants
+//   k_apply         src/algorithms/refinment.c:74-86,95-114  apply best move (batches, tabu)
 //                   src/algorithms/metaheuristic.c:226-240,40-59 (TABU variant)
+//   sweep_step(), BState, pipe_stream(): the step evaluation and row streaming the LDS sweeps share
 //
 // Tour representation on the device: position array ord[p] (+ inverse pos[],
 // successor succ[] and dnext[b] = c[b][succ b]).  A 2-opt move (a,b) reverses
