@@ -219,6 +219,49 @@ def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
     assert O.valid_tour(succ)
 
 
+def _grid_instance(kind):
+    if kind == "grid20":          # 400 lattice points: almost every delta value is shared by many pairs
+        g = np.arange(20, dtype=np.float64)
+        xy = np.stack(np.meshgrid(g * 10, g * 10), -1).reshape(-1, 2)
+    elif kind == "grid32x40":     # 1280 points, anisotropic lattice, shuffled node order
+        xy = np.stack(np.meshgrid(np.arange(32.0) * 7, np.arange(40.0) * 3), -1).reshape(-1, 2)
+        xy = xy[np.random.RandomState(5).permutation(len(xy))]
+    elif kind == "dups":          # every point twice (zero-length edges) plus a collinear run
+        base = np.random.RandomState(9).randint(0, 50, size=(150, 2)).astype(np.float64)
+        line = np.stack([np.arange(60.0), np.zeros(60)], -1)
+        xy = np.concatenate([base, base, line])
+    else:
+        raise KeyError(kind)
+    return np.ascontiguousarray(xy)
+
+
+@pytest.mark.parametrize("elem,kernel", COMBOS)
+@pytest.mark.parametrize("kind", ["grid20", "grid32x40", "dups"])
+def test_tie_heavy_instances(eng, T, O, kind, elem, kernel, fused):
+    """lattices and duplicate points: ties everywhere, so the (delta, a, b) order itself is what is
+    compared -- NN (ties to the lowest index), every move of the search, the final tour"""
+    if fused and kernel not in (2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
+    xy = _grid_instance(kind)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, 0)
+    g, gcost = eng.nn_tour(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    eng.set_option(T.OPT_HISTORY, 4096)
+    want = []
+    while True:
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        if d >= -1e-7:
+            break
+        want.append((min(mv), max(mv), float(d)))
+    got_cost, got_sweeps, rc = eng.two_opt(g)
+    assert rc == 0 and got_sweeps == len(want) + 1 and got_cost == cost and np.array_equal(g, succ)
+    ha, hb, hd = eng.history(len(want))
+    assert [(int(min(a, b)), int(max(a, b)), float(d)) for a, b, d in zip(ha, hb, hd)] == want
+
+
 def test_nn_all_under_deadline(eng, T, O, instances):
     """h_Greedy_iterative's cooperative deadline: the starts done form a prefix, the result is the
     first strictly best of that prefix"""
