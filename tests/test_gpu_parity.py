@@ -569,6 +569,40 @@ def test_matrix_free_tabu_and_att(mf, T, O, instances, golden):
     assert (res["cost"], res["start"]) == (want[1], want[2]) and np.array_equal(res["path"], want[0])
 
 
+@pytest.mark.parametrize("kind", ["EUC_2D", "CEIL_2D", "ATT"])
+@pytest.mark.parametrize("inst", ["dups", "grid20", "int1e6", "frac"])
+def test_matrix_free_kinds_and_ties(mf, T, O, kind, inst):
+    """the specialised integer weights of the matrix-free sweep (EUC_2D: hand-expanded correctly
+    rounded root; CEIL_2D on integer coordinates: exact integer ceil-sqrt; generic otherwise),
+    zero-length edges and lattices: every move against the oracle's matrix of the same kind"""
+    if inst in ("dups", "grid20"):
+        xy = _grid_instance(inst)
+    elif inst == "int1e6":
+        xy = np.random.RandomState(3).randint(0, 1500000, size=(700, 2)).astype(np.float64)
+    else:
+        xy = np.random.RandomState(4).uniform(-5000, 5000, size=(600, 2))
+    k = getattr(O, kind)
+    c = O.cost_matrix(xy, k)
+    mf.set_points(xy, k); mf.build_costs()
+    assert mf.info()["matrix_free"] == 1
+    succ, cost = O.nn_tour(c, 0)
+    g, gcost = mf.nn_tour(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    mf.set_option(T.OPT_HISTORY, 4096)
+    want = []
+    while True:
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        if d >= -1e-7:
+            break
+        want.append((min(mv), max(mv), float(d)))
+    got_cost, got_sweeps, rc = mf.two_opt(g)
+    assert mf.info()["kernel"] == 4
+    assert rc == 0 and got_sweeps == len(want) + 1 and got_cost == cost and np.array_equal(g, succ)
+    ha, hb, hd = mf.history(len(want))
+    assert [(int(min(a, b)), int(max(a, b)), float(d)) for a, b, d in zip(ha, hb, hd)] == want
+    mf.set_option(T.OPT_HISTORY, 0)
+
+
 def test_matrix_free_d18512(mf, T, O, golden):
     xy, _ = O.read_tsplib(data_path("d18512"))
     mf.set_points(xy); mf.build_costs()

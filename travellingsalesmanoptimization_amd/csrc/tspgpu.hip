@@ -1641,6 +1641,150 @@ __global__ void __launch_bounds__(256) k_gather_spts(Tours S, int n, int slot0, 
     spts[(size_t)blockIdx.y * n + b] = pts[S.succ[(size_t)t * n + b]];
 }
 
+// One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
+// correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
+// and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
+// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
+// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
+// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
+constexpr int KIND_CEIL_INT = 3;
+template <int KIND>
+__device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
+{
+    const double dx = bx - ax, dy = by - ay;
+    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
+    if constexpr (KIND == TSPGPU_EUC_2D) {
+        const float x = (float)sq;
+        const float r = __builtin_amdgcn_sqrtf(x);
+        const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+        const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+        float c = 0.0f >= em ? rm : r;
+        c = 0.0f < ep ? rp : c;
+        return (int)((double)c + 0.5);
+    } else if constexpr (KIND == KIND_CEIL_INT) {
+        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
+        k = k * k < sq ? k + 1.0 : k;
+        k = k * k < sq ? k + 1.0 : k;
+        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
+        return (int)k;
+    } else return (int)edge_weight(ax, ay, bx, by, KIND);
+}
+
+// ---------------------------------------------------------------------------
+// Matrix-free sweep, second form (costs below 2^25, n < 131 072): a thread holds FOUR
+// consecutive b's (their points, the points of their successors, c[b][succ b]: 16-byte loads),
+// a wave 256 -- a block, so the block ownership of sweep_step() applies (a wave is wholly
+// in, wholly out, or holds a's own block; the neighbours of a need no mask: their delta is
+// exactly 0) -- and for a fixed a the labels of the four b's ascend with the slot number, so
+// per pair ONE 32-bit min on (w1 + w2 - c[b][sb]) << 2 | v keeps the reference's tie order.
+// Per pair that leaves the two weights and three integer instructions.
+// ---------------------------------------------------------------------------
+template <int KIND, bool TABU>
+__global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
+{
+    constexpr int RUN = 8, VB = 4, VSH = 2;     // 4 b's per thread: 8 need > 128 registers (two waves per SIMD only)
+    __shared__ int nodes_s[RUN + 2];
+    __shared__ double2 npt[RUN + 1];
+    __shared__ int dstep[RUN];
+    __shared__ Partial scratch[16];
+    const int n = A.n;
+    const int t = A.slot0 + blockIdx.y;
+    if (A.S.done[t]) return;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int *ord = A.S.ord + (size_t)t * n;
+    const int *succ = A.S.succ + (size_t)t * n;
+    const int *dnb = dnb_of<int>(A.S, t, n);
+    const double2 *pts = A.pts;
+    const double2 *spts = A.spts + (size_t)blockIdx.y * n;
+    const int dir = A.S.dir[t];
+    int *nodes = nodes_s + 1;
+
+    int iter = 0, tenure = 0;
+    if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
+
+    const int p0 = blockIdx.x * RUN;
+    const int cnt = min(RUN, n - p0);
+    if (tid <= cnt + 1) {
+        const int i = tid - 1;
+        const int v = ord[wrap(p0 + (dir > 0 ? i : cnt - i), n)];
+        int flag = 0;
+        if constexpr (TABU) flag = is_tabu(A.tabu_list, v, iter, tenure) ? TABU_NODE : 0;
+        nodes[i] = v | flag;
+        if (i >= 0) npt[i] = pts[v];
+        if (i >= 0 && i < cnt) dstep[i] = dnb[v];      // c[a_i][succ a_i]
+    }
+    __syncthreads();
+
+    long long best_k = TABU ? 0x7fffffffffffffffll : 0ll;   // (delta << 34 | min(a,b) << 17 | max(a,b)); 0 = no improving move
+    const int wave_lane0 = __builtin_amdgcn_readfirstlane(tid & ~63);
+    const int NB = (n + 64 * VB - 1) / (64 * VB);
+
+    for (int base = 0; base < n; base += BT * VB) {
+        const int w0 = base + wave_lane0 * VB;           // this wave's first b
+        if (w0 >= n) continue;
+        const int b0 = base + tid * VB;
+        double2 pb[VB], sp[VB];
+        int dn[VB];
+        unsigned skm = 0;
+#pragma unroll
+        for (int v = 0; v < VB; v++) {
+            const int bb = min(b0 + v, n - 1);
+            pb[v] = pts[bb];
+            sp[v] = spts[bb];
+            dn[v] = dnb[bb];
+            if constexpr (TABU)
+                if (is_tabu(A.tabu_list, bb, iter, tenure) || is_tabu(A.tabu_list, succ[bb], iter, tenure)) skm |= 1u << v;
+        }
+        const int blkb = w0 / (64 * VB);
+#pragma unroll
+        for (int s = 0; s < RUN; s++) {
+            if (s >= cnt) break;
+            const int a_raw = __builtin_amdgcn_readfirstlane(nodes[s]), sa_raw = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+            if constexpr (TABU) { if ((a_raw | sa_raw) & TABU_NODE) continue; }
+            const int a = a_raw & NODE_MASK, sa = sa_raw & NODE_MASK;
+            const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]) & NODE_MASK;
+            int d = blkb - a / (64 * VB);
+            if (d < 0) d += NB;
+            const bool self = d == 0;
+            if (!self && !(2 * d < NB || (2 * d == NB && a / (64 * VB) < blkb))) continue;   // the other orientation's
+            const bool hit = TABU && ((unsigned)(am - w0) < (unsigned)(64 * VB) || (unsigned)(sa - w0) < (unsigned)(64 * VB));
+            const bool clean = !self && !hit && w0 + 64 * VB <= n;
+            const double2 pa = npt[s], ps = npt[s + 1];
+            auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
+                constexpr bool CHECK = decltype(check_tag)::value;
+                int m = 0x7fffffff;
+#pragma unroll
+                for (int v = 0; v < VB; v++) {
+                    int dl = edge_w<KIND>(pa.x, pa.y, pb[v].x, pb[v].y) + edge_w<KIND>(ps.x, ps.y, sp[v].x, sp[v].y) - dn[v];
+                    if constexpr (CHECK) {
+                        const int b = b0 + v;
+                        const bool ok = ((b > a) | !self) & (b < n) & (!TABU | ((b != am) & (b != sa)));
+                        dl = ok ? dl : MASKED32;
+                    }
+                    if constexpr (TABU) dl = ((skm >> v) & 1u) ? MASKED32 : dl;
+                    m = min(m, (dl << VSH) | v);
+                }
+                const int b = b0 + (m & (VB - 1));
+                const long long key = ((long long)((m >> VSH) - dstep[s]) << 34) | ((long long)min(a, b) << 17) | (long long)max(a, b);
+                best_k = key < best_k ? key : best_k;
+            };
+            if (clean) pairs(std::false_type{}); else pairs(std::true_type{});
+        }
+    }
+    const int bd = (int)(best_k >> 34);
+    const int la = (int)((best_k >> 17) & 0x1ffff), lb = (int)(best_k & 0x1ffff);
+    const bool have = TABU ? bd < MASKED32 / 2 : bd < 0;
+    double d = (double)bd;
+    u64 key;
+    if (!have) { d = TABU ? DBL_MAX : 0.0; key = TABU ? KEY_NONE : 0; }
+    else key = ((u64)(unsigned)la << 32) | (unsigned)lb;
+    block_argmin(d, key, scratch);
+    if (tid == 0) {
+        Partial o; o.d = d; o.key = key;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+    }
+}
+
 template <bool TABU>
 __global__ void __launch_bounds__(256) k_sweep_otf(SweepArgs A)
 {
@@ -1982,6 +2126,7 @@ struct tspgpu_ctx {
     int opt_otf = 0;         // 0 auto, 1 force matrix-free, 2 never
     double2 *d_spts = nullptr; size_t spts_cap = 0;
     double cost_bound = 0;   // upper bound of any entry the uploaded points can produce
+    bool int_coords = false; // every coordinate an integer below 2^25 in magnitude
     int *d_flags = nullptr;
 
     // tours
@@ -2350,6 +2495,13 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
         hipLaunchKernelGGL(k_gather_spts, dim3((n + 255) / 256, ntours), dim3(256), 0, ctx->stream, ctx->S, n, slot0, ctx->d_pts, ctx->d_spts);
         HIP_TRY(hipGetLastError());
         const void *fo = tabu ? (const void *)k_sweep_otf<true> : (const void *)k_sweep_otf<false>;
+        if (ctx->cost_bound < 33554432.0 && n < 131072) {     // 2^25, 17-bit labels
+            const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+#define OTF8(K) (tabu ? (const void *)k_sweep_otf8<K, true> : (const void *)k_sweep_otf8<K, false>)
+            fo = kind == TSPGPU_EUC_2D ? OTF8(TSPGPU_EUC_2D) : kind == TSPGPU_ATT ? OTF8(TSPGPU_ATT)
+               : kind == KIND_CEIL_INT ? OTF8(KIND_CEIL_INT) : OTF8(TSPGPU_CEIL_2D);
+#undef OTF8
+        }
         void *ao[] = {&A};
         HIP_TRY(hipLaunchKernel(fo, dim3(ctx->plan_G, ntours), dim3(256), ao, 0, ctx->stream));
         return E_OK;
@@ -2802,6 +2954,9 @@ int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_
     ctx->kind = edge_weight_type;
     ctx->have_points = true;
     double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
+    ctx->int_coords = true;
+    for (int i = 0; i < 2 * n; i++)
+        if (!(std::fabs(xy[i]) < 33554432.0) || xy[i] != std::floor(xy[i])) { ctx->int_coords = false; break; }
     for (int i = 1; i < n; i++) {
         x0 = std::min(x0, xy[2 * i]); x1 = std::max(x1, xy[2 * i]);
         y0 = std::min(y0, xy[2 * i + 1]); y1 = std::max(y1, xy[2 * i + 1]);
