@@ -85,8 +85,10 @@ def test_three_ranks_float_costs_allgather_path(O):
 def test_pack_key_and_sharding():
     sys.path.insert(0, ROOT)
     from travellingsalesmanoptimization_amd import multistart as M
-    assert M.pack_key(266290.0, 1001) == (266290 << 32) | 1001
+    assert M.pack_key(266290.0, 1001, 3) == (266290 << 32) | (1001 << 8) | 3
     assert M.pack_key(1121.03, 5) is None
+    # the rank in the low byte never decides: a start lives on exactly one rank
+    assert M.pack_key(7657.0, 12, 7) < M.pack_key(7657.0, 13, 0) < M.pack_key(7658.0, 0, 0)
     # lowest cost wins; ties go to the lowest start id (the strict < of tsp.c:671 under
     # ascending iteration order)
     keys = [M.pack_key(7657.0, 51), M.pack_key(7657.0, 12), M.pack_key(7700.0, 0)]
