@@ -1233,7 +1233,10 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
 // nodes and its own cells of ord.  No separate apply launch, no gather, no inter-workgroup
 // communication inside a launch.  k_fused_begin / k_fused_end convert from / to the Tours form.
 // ---------------------------------------------------------------------------
-template <typename AT>
+// PACKED (uint16 cells, n < 65536): the per-node records are 16-bit -- pos as uint16, (nl, nr) and
+// (dl, dr) as halves of one 32-bit word each, in the same buffers -- which halves what every
+// workgroup of every launch reads of them.
+template <typename AT, bool PACKED>
 __global__ void __launch_bounds__(256) k_fused_begin(Tours S, Fused F, int n, int slot0)
 {
     const int t = slot0 + blockIdx.y;
@@ -1244,11 +1247,17 @@ __global__ void __launch_bounds__(256) k_fused_begin(Tours S, Fused F, int n, in
         const AT *dp = reinterpret_cast<const AT *>(S.dpos + tn);
         const int v = ord[p], pl = wrap(p - 1, n);
         F.ord[1][tn + p] = v;
-        F.pos[1][tn + v] = p;
-        F.nl[1][tn + v] = ord[pl];
-        F.nr[1][tn + v] = ord[wrap(p + 1, n)];
-        reinterpret_cast<AT *>(F.dl[1] + tn)[v] = dp[pl];
-        reinterpret_cast<AT *>(F.dr[1] + tn)[v] = dp[p];
+        if constexpr (PACKED) {
+            (reinterpret_cast<u16 *>(F.pos[1]) + tn)[v] = (u16)p;
+            (reinterpret_cast<unsigned *>(F.nl[1]) + tn)[v] = (unsigned)ord[pl] | ((unsigned)ord[wrap(p + 1, n)] << 16);
+            (reinterpret_cast<unsigned *>(F.dl[1]) + tn)[v] = (unsigned)dp[pl] | ((unsigned)dp[p] << 16);
+        } else {
+            F.pos[1][tn + v] = p;
+            F.nl[1][tn + v] = ord[pl];
+            F.nr[1][tn + v] = ord[wrap(p + 1, n)];
+            reinterpret_cast<AT *>(F.dl[1] + tn)[v] = dp[pl];
+            reinterpret_cast<AT *>(F.dr[1] + tn)[v] = dp[p];
+        }
     }
     if (p == 0) {
         F.dir[1][t] = S.dir[t]; F.k[1][t] = 0; F.cost[1][t] = S.cost[t]; F.stop[1][t] = 0; F.stop[0][t] = 0;
@@ -1257,7 +1266,7 @@ __global__ void __launch_bounds__(256) k_fused_begin(Tours S, Fused F, int n, in
     }
 }
 
-template <typename AT>
+template <typename AT, bool PACKED>
 __global__ void __launch_bounds__(256) k_fused_end(Tours S, Fused F, int n, int slot0, int last_parity)
 {
     const int t = slot0 + blockIdx.y;
@@ -1266,9 +1275,18 @@ __global__ void __launch_bounds__(256) k_fused_end(Tours S, Fused F, int n, int 
     const int c = S.done[t] ? F.cur[t] : last_parity;   // not finished (deadline): the last state written
     const int dir = F.dir[c][t];
     if (v < n) {
-        const int p = F.pos[c][tn + v];
-        const int l = F.nl[c][tn + v], r = F.nr[c][tn + v];
-        const AT dl = reinterpret_cast<const AT *>(F.dl[c] + tn)[v], dr = reinterpret_cast<const AT *>(F.dr[c] + tn)[v];
+        int p, l, r;
+        AT dl, dr;
+        if constexpr (PACKED) {
+            p = (reinterpret_cast<const u16 *>(F.pos[c]) + tn)[v];
+            const unsigned lr = (reinterpret_cast<const unsigned *>(F.nl[c]) + tn)[v], dd = (reinterpret_cast<const unsigned *>(F.dl[c]) + tn)[v];
+            l = (int)(lr & 0xffffu); r = (int)(lr >> 16);
+            dl = (AT)(dd & 0xffffu); dr = (AT)(dd >> 16);
+        } else {
+            p = F.pos[c][tn + v];
+            l = F.nl[c][tn + v]; r = F.nr[c][tn + v];
+            dl = reinterpret_cast<const AT *>(F.dl[c] + tn)[v]; dr = reinterpret_cast<const AT *>(F.dr[c] + tn)[v];
+        }
         S.ord[tn + p] = v;
         S.pos[tn + v] = p;
         reinterpret_cast<AT *>(S.dpos + tn)[p] = dr;
@@ -1338,17 +1356,26 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
                     K2 = PAY ? ((c_i64 *)A.F.bestkey)[t * 4 + 2] : 0;      // all three slots: no trip behind k_done
     // the old records of the own b's depend on nothing either: in flight during the reduction
     // (up to 16 b's per thread; beyond that the registers are needed elsewhere: loaded chunk by chunk below)
+    // uint16 cells: 16-bit records (k_fused_begin): pos as uint16, (nl | nr << 16), (dl | dr << 16)
     constexpr bool HOIST = NCH * V <= 16;
     constexpr int HC = HOIST ? NCH : 1;
-    int qv[HC][V], lv[HC][V], rv[HC][V];
-    AT dlv[HC][V], drv[HC][V];
+    constexpr int QW = PAY ? 1 : V;                     // PAY: kept packed in registers, unpacked at use
+    int qv[HC][V], lv[HC][V], rv[HC][QW];
+    AT dlv[HC][V], drv[HC][QW];
+    u16 q16[HC][PAY ? V : 1];
     auto load_old = [&](int c, int slot) __attribute__((always_inline)) {
         const int b0 = min((c * (int)blockDim.x + (int)threadIdx.x) * V, ld - V);
-        load_run<V>(pos_o + b0, qv[slot]);
-        load_run<V>(nl_o + b0, lv[slot]);
-        load_run<V>(nr_o + b0, rv[slot]);
-        load_run<V>(dl_o + b0, dlv[slot]);
-        load_run<V>(dr_o + b0, drv[slot]);
+        if constexpr (PAY) {
+            load_run<V>(reinterpret_cast<const u16 *>(A.F.pos[rd]) + tn + b0, q16[slot]);
+            load_run<V>(reinterpret_cast<const int *>(A.F.nl[rd]) + tn + b0, lv[slot]);
+            load_run<V>(reinterpret_cast<const int *>(A.F.dl[rd]) + tn + b0, dlv[slot]);
+        } else {
+            load_run<V>(pos_o + b0, qv[slot]);
+            load_run<V>(nl_o + b0, lv[slot]);
+            load_run<V>(nr_o + b0, rv[slot]);
+            load_run<V>(dl_o + b0, dlv[slot]);
+            load_run<V>(dr_o + b0, drv[slot]);
+        }
     };
     if constexpr (HOIST) {
 #pragma unroll
@@ -1468,12 +1495,19 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 #pragma unroll
         for (int v = 0; v < V; v++) {
             const int b = (c * BT + tid) * V + v;
-            int r = qv[hc][v] - lo;
+            int q_o, l_o, r_o;
+            AT dl_v, dr_v;
+            if constexpr (PAY) {
+                q_o = (int)q16[hc][v];
+                l_o = (int)((unsigned)lv[hc][v] & 0xffffu); r_o = (int)((unsigned)lv[hc][v] >> 16);
+                dl_v = (AT)((unsigned)dlv[hc][v] & 0xffffu); dr_v = (AT)((unsigned)dlv[hc][v] >> 16);
+            } else { q_o = qv[hc][v]; l_o = lv[hc][v]; r_o = rv[hc][v]; dl_v = dlv[hc][v]; dr_v = drv[hc][v]; }
+            int r = q_o - lo;
             if (r < 0) r += n;
             const bool inr = r < M;
-            const int qn = inr ? wrap(lo + M - 1 - r, n) : qv[hc][v];
-            int l2 = inr ? rv[hc][v] : lv[hc][v], r2 = inr ? lv[hc][v] : rv[hc][v];
-            AT dl2 = inr ? drv[hc][v] : dlv[hc][v], dr2 = inr ? dlv[hc][v] : drv[hc][v];
+            const int qn = inr ? wrap(lo + M - 1 - r, n) : q_o;
+            int l2 = inr ? r_o : l_o, r2 = inr ? l_o : r_o;
+            AT dl2 = inr ? dr_v : dl_v, dr2 = inr ? dl_v : dr_v;
             if (move) {
                 if (b == x0) { r2 = x2; dr2 = wA; }
                 if (b == x3) { l2 = x1; dl2 = wB; }
@@ -1481,9 +1515,15 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
                 if (b == x2) { l2 = x0; dl2 = wA; }
             }
             if (mine && b < n) {
-                A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
-                reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
-                reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
+                if constexpr (PAY) {
+                    (reinterpret_cast<u16 *>(A.F.pos[wr]) + tn)[b] = (u16)qn;
+                    (reinterpret_cast<unsigned *>(A.F.nl[wr]) + tn)[b] = (unsigned)l2 | ((unsigned)r2 << 16);
+                    (reinterpret_cast<unsigned *>(A.F.dl[wr]) + tn)[b] = (unsigned)dl2 | ((unsigned)dr2 << 16);
+                } else {
+                    A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
+                    reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
+                    reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
+                }
             }
             const int sb = b < n ? (ndir > 0 ? r2 : l2) : 0;
             const AT dn = ndir > 0 ? dr2 : dl2;
@@ -2595,8 +2635,10 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
     const int n = ctx->n;
     const bool f64 = ctx->elem == TSPGPU_ELEM_F64;
     const dim3 grid1((n + 255) / 256, ntours);
-    if (f64) hipLaunchKernelGGL((k_fused_begin<double>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
-    else hipLaunchKernelGGL((k_fused_begin<int>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
+    const bool pk = ctx->elem == TSPGPU_ELEM_U16;
+    if (f64) hipLaunchKernelGGL((k_fused_begin<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
+    else if (pk) hipLaunchKernelGGL((k_fused_begin<int, true>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
+    else hipLaunchKernelGGL((k_fused_begin<int, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
     HIP_TRY(hipGetLastError());
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     const int K = std::max(2, ctx->opt_batch & ~1);
@@ -2649,8 +2691,9 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
         if (all) break;
         if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
     }
-    if (f64) hipLaunchKernelGGL((k_fused_end<double>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
-    else hipLaunchKernelGGL((k_fused_end<int>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    if (f64) hipLaunchKernelGGL((k_fused_end<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    else if (pk) hipLaunchKernelGGL((k_fused_end<int, true>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    else hipLaunchKernelGGL((k_fused_end<int, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
