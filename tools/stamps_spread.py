@@ -18,6 +18,8 @@ G = eng.info()["wgs_per_tour"]
 buf = np.zeros(G * 64, dtype=np.uint64)
 eng._ck(eng.L.tspgpu_debug_stamps(eng.ctx, buf.ctypes.data, len(buf)))
 st = buf.reshape(G, 64).astype(np.int64)
+st = st[st[:, 0] > 0]                          # the two-halves form launches fewer, larger workgroups
+G = len(st)
 t0 = st[:, 0].min()
 us = (st - t0) / 100.0
 names = {0: "entry", 5: "key", 1: "derived", 2: "landed", 3: "steps", 4: "end"}
