@@ -837,18 +837,31 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
             AT g[V];
 #pragma unroll
             for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + B.sb[c][v]);
+            // the chunk's own winner first: for a fixed a the labels of consecutive b's ascend with
+            // v, so the first strictly smallest delta in v order is the reference's pick among
+            // them; only that one meets the running best (and its tie branch)
             auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
             constexpr bool CHECK = decltype(check_tag)::value;
+            AT dm = 0;
+            int bv = 0;
+            bool okm = false;
 #pragma unroll
             for (int v = 0; v < V; v++) {
-                const int b = b0 + v;
                 bool ok = true;
-                if constexpr (CHECK) ok = valid(b);
+                if constexpr (CHECK) ok = valid(b0 + v);
                 const AT made = (AT)vget(xa, v) + g[v];
                 const AT kept = d_a + B.dn[c][v];
                 const AT delta = made - kept;               // refinment.c:58-60
-                const bool lt = ok & (delta < q.d);
-                bool eq = ok & (delta == q.d);
+                const bool take = ok & (!okm | (delta < dm));
+                dm = take ? delta : dm;
+                bv = take ? v : bv;
+                okm = okm | ok;
+            }
+            {
+                const int b = b0 + bv;
+                const AT delta = dm;
+                const bool lt = okm & (delta < q.d);
+                bool eq = okm & (delta == q.d);
                 if constexpr (!TABU) eq &= delta < (AT)0;
                 if (__ballot(eq)) {               // wave-uniform and rare: same delta, lower (a,b) wins
                     if (eq) {
