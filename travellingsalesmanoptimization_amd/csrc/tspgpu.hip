@@ -806,31 +806,24 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
             AT g[V];
 #pragma unroll
             for (int v = 0; v < V; v++) g[v] = (AT)*reinterpret_cast<const T *>(bS + B.sb[c][v]);
-            // groups of 4 independent keys + a min tree each: short dependency chains, and the
-            // only serial dependency on the running best is one compare per chunk
+            // the chunk's own winner first (32-bit compares; for a fixed a the labels of consecutive
+            // b's ascend with v, so the first strictly smallest delta in v order is the reference's
+            // pick among them), then ONE 64-bit key meets the running best
             auto keys = [&](auto check_tag) __attribute__((always_inline)) {
                 constexpr bool CHECK = decltype(check_tag)::value;
-                constexpr int GR = V < 4 ? V : 4;
-                long long acc = 0x7fffffffffffffffll;
+                int dm = 0x7fffffff, bv = 0;
 #pragma unroll
-                for (int v0 = 0; v0 < V; v0 += GR) {
-                    long long key[GR];
-#pragma unroll
-                    for (int u = 0; u < GR; u++) {
-                        const int v = v0 + u;
-                        const int b = b0 + v;
-                        int delta = (int)vget(xa, v) + g[v] - (d_a + B.dn[c][v]);
-                        if constexpr (CHECK) delta = valid(b) ? delta : BIG;
-                        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-                        key[u] = (long long)(((u64)(unsigned)delta << 32) | lohi);
-                    }
-#pragma unroll
-                    for (int w = GR / 2; w >= 1; w /= 2)
-#pragma unroll
-                        for (int u = 0; u < w; u++) key[u] = key[u + w] < key[u] ? key[u + w] : key[u];
-                    acc = key[0] < acc ? key[0] : acc;
+                for (int v = 0; v < V; v++) {
+                    int delta = (int)vget(xa, v) + g[v] - (d_a + B.dn[c][v]);
+                    if constexpr (CHECK) delta = valid(b0 + v) ? delta : BIG;
+                    const bool take = delta < dm;
+                    dm = take ? delta : dm;
+                    bv = take ? v : bv;
                 }
-                q.k = acc < q.k ? acc : q.k;
+                const int b = b0 + bv;
+                const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+                const long long key = (long long)(((u64)(unsigned)dm << 32) | lohi);
+                q.k = key < q.k ? key : q.k;
             };
             if (clean) keys(std::false_type{}); else keys(std::true_type{});
         } else {
