@@ -219,6 +219,25 @@ def test_full_size_n4096_headline(eng, T, O, golden, elem, kernel, fused):
     assert O.valid_tour(succ)
 
 
+@pytest.mark.parametrize("elem,kernel,block,wgs,depth", [
+    (3, 3, 0, 1024, 0), (3, 3, 256, 0, 0), (3, 2, 512, 256, 2), (3, 2, 1024, 512, 4), (3, 1, 256, 512, 0),
+    (2, 2, 512, 256, 4), (2, 2, 1024, 256, 8), (2, 3, 0, 1024, 0), (1, 2, 1024, 256, 2), (1, 2, 512, 512, 4), (1, 1, 512, 1024, 0)])
+def test_plan_overrides_keep_the_trajectory(eng, T, O, instances, golden, elem, kernel, block, wgs, depth, fused):
+    """the tuning knobs (block size, workgroups per tour, prefetch depth) change the launch
+    geometry, never the result: pr1002 to its golden local optimum under each of them"""
+    if fused and kernel not in (2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
+    xy, c = setup(eng, T, O, instances, "pr1002", elem, kernel)
+    eng.set_option(T.OPT_BLOCK, block); eng.set_option(T.OPT_WGS_PER_TOUR, wgs); eng.set_option(T.OPT_DEPTH, depth)
+    try:
+        g = golden["instances"]["pr1002"]["two_opt"]
+        succ, nn_cost = eng.nn_tour(0)
+        cost, sweeps, rc = eng.two_opt(succ)
+        assert rc == 0 and (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+    finally:
+        eng.set_option(T.OPT_BLOCK, 0); eng.set_option(T.OPT_WGS_PER_TOUR, 0); eng.set_option(T.OPT_DEPTH, 0)
+
+
 def _grid_instance(kind):
     if kind == "grid20":          # 400 lattice points: almost every delta value is shared by many pairs
         g = np.arange(20, dtype=np.float64)
