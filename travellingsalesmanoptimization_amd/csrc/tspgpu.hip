@@ -2473,6 +2473,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         if (nch > (ctx->elem == TSPGPU_ELEM_U16 ? 1 : 2)) { BT = res_bt; nch = res_nch; }
         P = res_P();
         if (ctx->opt_wgs > 0) P = std::max(2, std::min(P, (n + ctx->opt_wgs - 1) / ctx->opt_wgs));
+        // a single small tour is latency-bound: shorter runs on more workgroups (up to two per CU)
+        // cut the step chain; the extra row per run costs nothing at these sizes (measured:
+        // n=1024 11.1 -> 8.7 us per sweep, n=2048 11.9 -> 10.5)
+        else if (ntours == 1) P = std::max(2, std::min(P, (n + 2 * ctx->cus - 1) / (2 * ctx->cus)));
         G = (n + P - 1) / P;
         if (G > MAX_WGS_PER_TOUR) return fail(ctx, E_EXHAUSTED, "resident sweep: %d workgroups per tour exceed %d", G, MAX_WGS_PER_TOUR);
         ctx->plan_D = 0;
