@@ -105,7 +105,7 @@ def main():
     ap.add_argument("--wgs", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32)
-    ap.add_argument("--cpu-sweeps", type=int, default=150, help="bounded CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sweeps", type=int, default=300, help="bounded CPU baseline sample (0 = skip)")
     ap.add_argument("--batch-starts", type=int, default=64, help="starts of the batched multi-start leg (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
     args = ap.parse_args()
