@@ -153,6 +153,15 @@ int tspgpu_tour_nn(tspgpu_ctx *ctx, int slot, int start);
 int tspgpu_tour_copy(tspgpu_ctx *ctx, int dst, int src);
 /* sweep slot to its local optimum (max_sweeps < 0: no cap) */
 int tspgpu_tour_two_opt(tspgpu_ctx *ctx, int slot, long max_sweeps, double time_left_s, long *sweeps);
+/* Intra-sweep sharding ("optional, config 5": one sweep of a large instance split over
+ * the GPUs of a node).  Every rank holds the same tour in `slot`; tspgpu_tour_sweep_part evaluates
+ * the runs [part*G/nparts, (part+1)*G/nparts) of ONE sweep (refinment.c:49-69) and returns the best
+ * pair found there (delta 0, a = b = 0: nothing improving in this part); after the ranks have
+ * agreed on the minimum of (delta, a, b) -- one MIN all-reduce -- each applies it with
+ * tspgpu_tour_apply_move (refinment.c:74-86,95-114), which also counts the sweep; a delta >= 0
+ * marks the slot as locally optimal.  Symmetric matrices only. */
+int tspgpu_tour_sweep_part(tspgpu_ctx *ctx, int slot, int part, int nparts, double *delta, int *a, int *b);
+int tspgpu_tour_apply_move(tspgpu_ctx *ctx, int slot, int a, int b, double delta);
 /* fetch slot's successor array / cost / last delta */
 int tspgpu_tour_store(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta);
 /* launch the sweep kernel alone `reps` times on slot (no move applied) and

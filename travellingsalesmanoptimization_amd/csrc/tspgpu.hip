@@ -534,6 +534,7 @@ struct SweepArgs {
     Tours S;
     const void *mat;
     int n, ld, slot0, P;     // P = array positions (tour edges) per workgroup
+    int g0;                  // first workgroup (run) of this launch: > 0 only when a sweep is sharded over ranks
     int symmetric;
     int ablate;              // diagnostics only: 1 = no pair evaluation, 2 = no row traffic (results are wrong)
     unsigned long long *stamps; // diagnostics only: 64 wall-clock stamps (10 ns ticks) per workgroup, or null
@@ -609,7 +610,7 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     AT best_d = TABU ? Elem<T>::lim() : (AT)0;
     u64 best_key = TABU ? KEY_NONE : 0; // key 0 cannot be beaten on a tie: "no move" is (0, 0)
 
-    const int p0 = blockIdx.x * A.P;
+    const int p0 = ((int)blockIdx.x + A.g0) * A.P;
     const int cnt = min(A.P, n - p0);
     for (int s = 0; s < cnt; s++) {
         const int p = p0 + s, p1 = p + 1 == n ? 0 : p + 1;
@@ -648,7 +649,7 @@ __global__ void __launch_bounds__(1024) k_sweep_simple(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
     }
 }
 
@@ -1027,7 +1028,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
     STAMP(0);
-    const int p0 = blockIdx.x * A.P;
+    const int p0 = ((int)blockIdx.x + A.g0) * A.P;
     const int cnt = min(A.P, n - p0);
     // (host guarantees cnt >= 1 for every launched workgroup)
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
@@ -1077,7 +1078,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
     }
 #undef STAMP
 }
@@ -1122,7 +1123,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
     STAMP(0);
-    const int p0 = blockIdx.x * A.P;
+    const int p0 = ((int)blockIdx.x + A.g0) * A.P;
     const int cnt = min(A.P, n - p0);
     // the run in TOUR order: nodes[s] = a of step s, nodes[s+1] = its successor, nodes[-1] = its predecessor
     // (tabu: bit 30 marks a tabu node, so that the steps need no global read for it)
@@ -1220,7 +1221,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
     }
     STAMP(4);
 #undef STAMP
@@ -1472,7 +1473,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         return r < M ? wrap(lo + M - 1 - r, n) : p;
     };
 
-    const int p0 = blockIdx.x * A.P;
+    const int p0 = ((int)blockIdx.x + A.g0) * A.P;
     const int cnt = min(A.P, n - p0);
     // the run in TOUR order on the NEW state; this workgroup also writes its cells of the new ord
     for (int i = tid - 1; i <= cnt; i += BT) {
@@ -1748,7 +1749,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
 
-    const int p0 = blockIdx.x * RUN;
+    const int p0 = ((int)blockIdx.x + A.g0) * RUN;
     const int cnt = min(RUN, n - p0);
     if (tid <= cnt + 1) {
         const int i = tid - 1;
@@ -1827,7 +1828,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
     }
 }
 
@@ -1856,7 +1857,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf(SweepArgs A)
     int iter = 0, tenure = 0;
     if constexpr (TABU) { iter = A.tabu->iter; tenure = A.tabu->tenure; }
 
-    const int p0 = blockIdx.x * RUN;
+    const int p0 = ((int)blockIdx.x + A.g0) * RUN;
     const int cnt = min(RUN, n - p0);
     if (tid <= cnt + 1) {
         const int i = tid - 1;
@@ -1938,7 +1939,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf(SweepArgs A)
     block_argmin(d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
-        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x] = o;
+        A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
     }
 }
 
@@ -2529,12 +2530,16 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     return E_OK;
 }
 
-static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
+// g0 / gcount: the workgroups (runs) to launch; gcount < 0 = all of them (a sharded sweep launches a part)
+static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g0 = 0, int gcount = -1)
 {
     SweepArgs A;
+    memset(&A, 0, sizeof A);
     A.S = ctx->S;
     A.mat = ctx->d_mat;
     A.n = ctx->n; A.ld = ctx->ld; A.slot0 = slot0; A.P = ctx->plan_P;
+    A.g0 = g0;
+    const int G = gcount < 0 ? ctx->plan_G : gcount;
     A.symmetric = ctx->symmetric ? 1 : 0;
     A.ablate = ctx->opt_ablate;
     A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
@@ -2553,14 +2558,25 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu)
 #undef OTF8
         }
         void *ao[] = {&A};
-        HIP_TRY(hipLaunchKernel(fo, dim3(ctx->plan_G, ntours), dim3(256), ao, 0, ctx->stream));
+        HIP_TRY(hipLaunchKernel(fo, dim3(G, ntours), dim3(256), ao, 0, ctx->stream));
         return E_OK;
     }
     const void *fn = ctx->plan_kernel == 3 ? res_kernel(ctx->elem, ctx->plan_NCH, tabu)
                    : ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
     void *args[] = {&A};
-    HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
+    HIP_TRY(hipLaunchKernel(fn, dim3(G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
     return E_OK;
+}
+
+// partials of one tour := {the given move, nothing else}: what k_apply then applies (sharded sweeps)
+__global__ void k_set_move(Tours S, int slot, int G, double d, u64 key)
+{
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    Partial o;
+    o.d = g == 0 ? d : 0.0;
+    o.key = g == 0 ? key : 0;
+    S.partial[(size_t)slot * S.pstride + g] = o;
 }
 
 static int launch_apply(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, bool resident_tabu)
@@ -3405,6 +3421,50 @@ int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, d
     *best_cost = best; *best_start = arg;
     if (total_sweeps) *total_sweeps = sweeps;
     return late ? E_DEADLINE : E_OK;
+}
+
+int tspgpu_tour_sweep_part(tspgpu_ctx *ctx, int slot, int part, int nparts, double *delta, int *a, int *b)
+{
+    if (!ctx || !delta || !a || !b || slot < 0 || slot >= ctx->tcap || nparts <= 0 || part < 0 || part >= nparts)
+        return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if (!ctx->symmetric) return fail(ctx, E_PRECOND, "a sharded sweep needs a symmetric matrix (both orientations of a pair live in different parts otherwise)");
+    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    const int G = ctx->plan_G;
+    const int g_lo = (int)((long)part * G / nparts), g_hi = (int)((long)(part + 1) * G / nparts);
+    *delta = 0.0; *a = 0; *b = 0;
+    if (g_hi <= g_lo) return E_OK;
+    if ((rc = launch_sweep(ctx, slot, 1, false, g_lo, g_hi - g_lo))) return rc;
+    std::vector<Partial> h((size_t)(g_hi - g_lo));
+    HIP_TRY(hipMemcpyAsync(h.data(), ctx->S.partial + (size_t)slot * ctx->S.pstride + g_lo, h.size() * sizeof(Partial),
+                           hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    double d = 0.0;
+    u64 key = 0;
+    for (const Partial &q : h)
+        if (q.d < d || (q.d == d && q.key < key)) { d = q.d; key = q.key; }     // (delta, a, b): the reference's order
+    if (d < TWO_OPT_EPS) { *delta = d; *a = (int)(key >> 32); *b = (int)(key & 0xffffffffu); }
+    return E_OK;
+}
+
+int tspgpu_tour_apply_move(tspgpu_ctx *ctx, int slot, int a, int b, double delta)
+{
+    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad argument");
+    const int n = ctx->n;
+    if (a < 0 || b < 0 || a >= n || b >= n) return fail(ctx, E_INVALID, "move (%d,%d) outside [0,%d)", a, b, n);
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    const int G = ctx->plan_G;
+    const u64 key = delta < TWO_OPT_EPS ? (a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a) : 0;
+    hipLaunchKernelGGL(k_set_move, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, slot, G, delta < TWO_OPT_EPS ? delta : 0.0, key);
+    HIP_TRY(hipGetLastError());
+    if ((rc = launch_apply(ctx, slot, 1, false, false))) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return E_OK;
 }
 
 int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean)

@@ -167,6 +167,16 @@ class Engine:
                       ok=(T_OK, DEADLINE_EXCEEDED))
         return s.value, rc
 
+    def tour_sweep_part(self, slot, part, nparts):
+        """one sweep's runs [part*G/nparts, (part+1)*G/nparts) -> (delta, a, b); (0, 0, 0): nothing improving there"""
+        d, a, b = C.c_double(), C.c_int(), C.c_int()
+        self._ck(self.L.tspgpu_tour_sweep_part(self.ctx, int(slot), int(part), int(nparts), C.byref(d), C.byref(a), C.byref(b)))
+        return d.value, a.value, b.value
+
+    def tour_apply_move(self, slot, a, b, delta):
+        """apply the agreed move (delta >= 0: none -- the slot is locally optimal)"""
+        self._ck(self.L.tspgpu_tour_apply_move(self.ctx, int(slot), int(a), int(b), float(delta)))
+
     def tour_store(self, slot, want_path=True):
         path = np.empty(self.n, dtype=np.int32) if want_path else None
         c, d = C.c_double(), C.c_double()

@@ -98,3 +98,45 @@ def multistart_nn_2opt(solve_local, starts, device="cpu", group=None, n=None, to
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         total = int(t.item())
     return {"cost": cost, "start": start, "path": path, "sweeps": total}
+
+
+# ---------------------------------------------------------------------------
+# Intra-sweep sharding (optional, config 5): ONE local search whose every sweep is split
+# over the ranks -- worthwhile when a sweep is much longer than a collective (pla85900: 6.5 ms on
+# one GPU).  Every rank keeps an identical replica of the tour; per sweep each evaluates its share
+# of the runs (Engine.tour_sweep_part), ONE all-reduce(MIN) of the packed (delta, a, b) key picks
+# the reference's move, every rank applies it (Engine.tour_apply_move).
+# ---------------------------------------------------------------------------
+def pack_move(delta, a, b):
+    """(delta + 2^28):29 | a:17 | b:17 with a < b -- the reference's (delta, a, b) order as one int64"""
+    d = int(delta)
+    if d != delta or not (-(2 ** 28) < d <= 0) or not (0 <= a <= b < 2 ** 17):
+        return None
+    return ((d + 2 ** 28) << 34) | (int(a) << 17) | int(b)
+
+
+def sharded_two_opt(eng, slot, device="cpu", group=None, max_sweeps=-1):
+    """ref_2opt (refinment.c:3-37) on `slot`, every sweep sharded over the ranks of `group`.
+    Returns the number of sweeps (the final, non-improving one included, as the reference counts)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    sweeps = 0
+    while max_sweeps < 0 or sweeps < max_sweeps:
+        d, a, b = eng.tour_sweep_part(slot, rank, world)
+        if world > 1:
+            key = pack_move(d, a, b)
+            k = torch.tensor([UNPACKABLE if key is None else key], dtype=torch.int64, device=device)
+            dist.all_reduce(k, op=dist.ReduceOp.MIN, group=group)        # the one collective of a sweep
+            kmin = int(k.item())
+            if kmin != UNPACKABLE:
+                d, a, b = float((kmin >> 34) - 2 ** 28), (kmin >> 17) & 0x1FFFF, kmin & 0x1FFFF
+            else:                                                       # non-integer deltas somewhere
+                tri = torch.tensor([d, float(a), float(b)], dtype=torch.float64, device=device)
+                allt = [torch.empty_like(tri) for _ in range(world)]
+                dist.all_gather(allt, tri, group=group)
+                d, a, b = min((float(t[0]), int(t[1]), int(t[2])) for t in allt)
+        eng.tour_apply_move(slot, a, b, d)
+        sweeps += 1
+        if d >= 0:
+            break
+    return sweeps
