@@ -181,3 +181,26 @@ def test_binary_vns_pla85900_honours_deadline():
     assert rc == 0 and out.startswith("Cost: "), err
     assert float(out.split(":")[1]) <= g["nn_cost"]
     assert dt < 60, dt
+
+
+@pytest.mark.gpu
+def test_bench_line_contract():
+    """bench.py prints ONE JSON line carrying the driver's contract fields, the roofline object and
+    the parity gate (final cost of the headline workload)"""
+    import json, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sweeps", "3",
+                          "--no-other", "--batch-starts", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "GB/s"
+    assert d["final_cost_rank0"] == 488522.0 and d["config"]["sweeps_per_step_rank0"] == 609
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
+    assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
