@@ -124,13 +124,16 @@ def _shard_worker(rank, world, port, name, matrix_free, cap, q):
     import oracle as O
     import travellingsalesmanoptimization_amd as T
     from travellingsalesmanoptimization_amd import multistart
+    kind = O.EUC_2D
     if name.startswith("n"):
         xy = O.random_points(int(name[1:]), 123)
     else:
-        xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", name + ".tsp"))
+        xy, ewt = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", name + ".tsp"))
+        if name == "pla85900":
+            kind = O.CEIL_2D
     eng = T.Engine(0)
     eng.set_option(T.OPT_MATRIX_FREE, 1 if matrix_free else 2)
-    eng.set_points(xy); eng.build_costs()
+    eng.set_points(xy, kind); eng.build_costs()
     eng.tour_nn(0, 0)
     sweeps = multistart.sharded_two_opt(eng, 0, max_sweeps=cap)
     succ, cost, _ = eng.tour_store(0)
@@ -140,11 +143,16 @@ def _shard_worker(rank, world, port, name, matrix_free, cap, q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,matrix_free,cap", [("pr1002", False, -1), ("n1000", True, -1), ("d18512", False, 5), ("d18512", True, 5)])
+@pytest.mark.parametrize("name,matrix_free,cap", [("pr1002", False, -1), ("n1000", True, -1), ("d18512", False, 5), ("d18512", True, 5),
+                                                  ("pla85900", True, 3)])
 def test_sharded_sweep_two_ranks_one_gpu(name, matrix_free, cap):
     import json
     golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
-    g = (golden["instances"].get(name) or golden["random"]["n1000_s123"])["two_opt"]
+    if name == "pla85900":      # config 5: the case the sharded sweep exists for
+        m = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_large.json")))["pla85900"]["moves"][cap - 1]
+        g = {"sweeps": cap, "final_cost": m["cost"], "final_fnv": m["fnv"]}
+    else:
+        g = (golden["instances"].get(name) or golden["random"]["n1000_s123"])["two_opt"]
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
