@@ -160,7 +160,7 @@ def test_sharded_sweep_two_ranks_one_gpu(name, matrix_free, cap):
     procs = [ctx.Process(target=_shard_worker, args=(r, world, port, name, matrix_free, cap, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=120) for _ in range(world))
+    out = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
