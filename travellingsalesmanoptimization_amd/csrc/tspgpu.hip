@@ -2669,14 +2669,9 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     const int K = std::max(2, ctx->opt_batch & ~1);
     long issued = 0;
-    for (;;) {
-        // timing mode: one event pair around the whole batch (the launches of a batch run back to
-        // back, so batch time / K is the mean launch duration); only batches in which every launch
-        // swept are counted
-        if (ctx->opt_timing) {
-            while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
-            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        }
+    // one batch = K launches (a replayed hipGraph) + the copy of the `done` words
+    auto issue_batch = [&](int *h_done) -> int {
+        int rc = E_OK;
         if (ctx->opt_graph) {
             hipGraphExec_t exec = nullptr;
             for (auto &g : ctx->graphs)
@@ -2698,11 +2693,40 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
                 if ((rc = launch_fused(ctx, slot0, ntours, i & 1))) return rc;
         }
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->opt_timing)
-            HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_done, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+        return E_OK;
+    };
+    auto all_done = [&](const int *h_done) {
+        for (int i = 0; i < ntours; i++) if (!h_done[i]) return false;
+        return true;
+    };
+    if (!ctx->opt_timing) {
+        // Pipelined: the next batch is in the stream before the host looks at the previous one's
+        // `done` words, so the device never waits for the host (a graph launch + a sync cost
+        // ~20 us per batch otherwise); the price is one batch of immediately-returning launches
+        // after the tour has finished.
+        while ((int)ctx->ev.size() < 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+        int *buf[2] = {ctx->h_status, ctx->h_status + ctx->tcap};
+        if ((rc = issue_batch(buf[0]))) return rc;
+        HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        for (int cur = 0;; cur ^= 1) {
+            if ((rc = issue_batch(buf[cur ^ 1]))) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev[2 + (cur ^ 1)], ctx->stream));
+            HIP_TRY(hipEventSynchronize(ctx->ev[2 + cur]));
+            if (all_done(buf[cur])) break;
+            if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
+        }
+    } else
+    for (;;) {
+        // timing mode: one event pair around the whole batch (the launches of a batch run back to
+        // back, so batch time / K is the mean launch duration); only batches in which every launch
+        // swept are counted
+        while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        if ((rc = issue_batch(ctx->h_status))) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ctx->opt_timing) {
+        {
             int live = 0; // launches 0 .. nsweeps-1 swept (launch nsweeps only found the tour finished)
             for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
             if (issued + K <= live) {
@@ -2712,9 +2736,7 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
             }
         }
         issued += K;
-        bool all = true;
-        for (int i = 0; i < ntours; i++) if (!ctx->h_status[i]) { all = false; break; }
-        if (all) break;
+        if (all_done(ctx->h_status)) break;
         if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
     }
     if (f64) hipLaunchKernelGGL((k_fused_end<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
