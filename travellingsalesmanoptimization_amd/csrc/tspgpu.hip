@@ -50,6 +50,10 @@
 
 #include "tspgpu.h"
 
+#ifndef TSPGPU_RPC
+#define TSPGPU_RPC 3   // rows landed per chunk in the resident bodies (tools: -DTSPGPU_RPC=2 to compare)
+#endif
+
 // reference ERROR_CODE numbering (src/utils/errors.h:33-51)
 enum { E_OK = 0, E_INVALID = 3, E_DEADLINE = 4, E_EXHAUSTED = 8, E_PRECOND = 9,
        E_UNIMPL = 12, E_INTERNAL = 13, E_UNAVAILABLE = 14 };
@@ -1194,7 +1198,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
 
     // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
     // are in LDS runs while the later rows are still in flight (3 barriers in all for P = 8).
-    constexpr int RPC = 3;
+    constexpr int RPC = TSPGPU_RPC;
     {
         int s = 0;
 #pragma unroll
@@ -1588,7 +1592,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
     // are in LDS runs while the later rows are still in flight (3 barriers in all for P = 8).
-    constexpr int RPC = 3;
+    constexpr int RPC = TSPGPU_RPC;
     {
         int s = 0;
 #pragma unroll
