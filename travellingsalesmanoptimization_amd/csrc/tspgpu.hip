@@ -539,6 +539,7 @@ struct SweepArgs {
     const void *mat;
     int n, ld, slot0, P;     // P = array positions (tour edges) per workgroup
     int g0;                  // first workgroup (run) of this launch: > 0 only when a sweep is sharded over ranks
+    int tabu_lds;            // TABU: byte offset in the dynamic LDS of the per-node tabu bytes (n + 32 of them)
     int symmetric;
     int ablate;              // diagnostics only: 1 = no pair evaluation, 2 = no row traffic (results are wrong)
     unsigned long long *stamps; // diagnostics only: 64 wall-clock stamps (10 ns ticks) per workgroup, or null
@@ -708,6 +709,58 @@ __device__ __forceinline__ void bstate_set(BState<T, NCH> &B, int c, int v, int 
     } else {
         B.sb[c][v] = succ_b * (int)sizeof(T);
         B.dn[c][v] = skip ? -Elem<T>::big() : dn;   // kept = c[a][sa] + dn  ->  delta = made - kept ~ +BIG
+    }
+}
+
+// Per-b state of the pipelined / resident sweeps from the node-indexed view (succ, c[b][succ b]:
+// coalesced 16-byte loads), followed by ONE workgroup barrier.  Tabu: whether b or succ b is
+// tabu decides if b takes part at all; the stamps of the own b's are a coalesced read, and every
+// thread publishes its b's verdicts as bytes in LDS (behind the rows, A.tabu_lds bytes into the
+// dynamic LDS) so that the test of succ b is an LDS byte read after the barrier instead of a
+// random global gather per b.
+template <typename T, int NCH, bool TABU>
+__device__ __forceinline__ void load_bstate(BState<T, NCH> &B, const SweepArgs &A, unsigned char *smem, int t, int iter, int tenure)
+{
+    typedef typename Elem<T>::acc AT;
+    constexpr int V = Elem<T>::V;
+    const int n = A.n, ld = A.ld;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int *succ = A.S.succ + (size_t)t * n;
+    const AT *dnb = dnb_of<AT>(A.S, t, n);
+    int sv[NCH][V];
+    AT dv[NCH][V];
+    unsigned char *tb = smem + A.tabu_lds;
+    unsigned own = 0;                                   // tabu: bit c*V+v = own b is tabu
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int b0 = min((c * BT + tid) * V, ld - V);   // lanes past the row: masked
+        load_run<V>(succ + b0, sv[c]);
+        load_run<V>(dnb + b0, dv[c]);
+        if constexpr (TABU) {
+            int st[V];
+            load_run<V>(A.tabu_list + b0, st);
+            unsigned char flag[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const bool tb_v = iter - st[v] < tenure && st[v] != -1;   // metaheuristic.c:416-418
+                flag[v] = tb_v ? 1 : 0;
+                if (tb_v && (c * BT + tid) * V == b0) own |= 1u << (c * V + v);
+            }
+            if ((c * BT + tid) * V == b0) __builtin_memcpy(tb + b0, flag, V);   // V bytes, one store
+        }
+    }
+    __syncthreads(); // nodes[] (and the tabu bytes) visible
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int b = (c * BT + tid) * V + v;
+            const int sb = b < n ? sv[c][v] : 0;
+            bool sk = b >= n;
+            if constexpr (TABU)
+                if (b < n) sk = ((own >> (c * V + v)) & 1u) || tb[sb] != 0;
+            bstate_set<T, NCH>(B, c, v, sb, dv[c][v], sk, TABU);
+        }
     }
 }
 
@@ -1047,28 +1100,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     // per-thread state of the owned b's from the node-indexed view (coalesced 16-byte loads)
     BState<T, NCH> B;
     B.skm = 0;
-    {
-        const int *succ = A.S.succ + (size_t)t * n;
-        const AT *dnb = dnb_of<AT>(A.S, t, n);
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int b0 = min((c * BT + tid) * V, ld - V);
-            int sv[V];
-            AT dv[V];
-            load_run<V>(succ + b0, sv);
-            load_run<V>(dnb + b0, dv);
-#pragma unroll
-            for (int v = 0; v < V; v++) {
-                const int b = (c * BT + tid) * V + v;
-                const int sb = b < n ? sv[v] : 0;
-                bool sk = b >= n;
-                if constexpr (TABU)
-                    if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-                bstate_set<T, NCH>(B, c, v, sb, dv[v], sk, TABU);
-            }
-        }
-    }
-    __syncthreads(); // nodes[] visible
+    load_bstate<T, NCH, TABU>(B, A, smem, t, iter, tenure);   // (contains the barrier that also publishes nodes[])
     STAMP(1);
 
     Best q;
@@ -1143,28 +1175,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     // would only become usable after the last row has arrived.
     BState<T, NCH> B;
     B.skm = 0;
-    {
-        const int *succ = A.S.succ + (size_t)t * n;
-        const AT *dnb = dnb_of<AT>(A.S, t, n);
-#pragma unroll
-        for (int c = 0; c < NCH; c++) {
-            const int b0 = min((c * BT + tid) * V, ld - V);   // lanes past the row: masked
-            int sv[V];
-            AT dv[V];
-            load_run<V>(succ + b0, sv);
-            load_run<V>(dnb + b0, dv);
-#pragma unroll
-            for (int v = 0; v < V; v++) {
-                const int b = (c * BT + tid) * V + v;
-                const int sb = b < n ? sv[v] : 0;
-                bool sk = b >= n;
-                if constexpr (TABU)
-                    if (b < n) sk = is_tabu(A.tabu_list, b, iter, tenure) || is_tabu(A.tabu_list, sb, iter, tenure);
-                bstate_set<T, NCH>(B, c, v, sb, dv[v], sk, TABU);
-            }
-        }
-    }
-    __syncthreads(); // nodes[] visible
+    load_bstate<T, NCH, TABU>(B, A, smem, t, iter, tenure);   // (contains the barrier that also publishes nodes[])
     STAMP(1);
 
     // every row of the run in flight at once
@@ -2198,6 +2209,7 @@ struct tspgpu_ctx {
     // launch plan
     int plan_kernel = 0, plan_G = 0, plan_P = 0, plan_BT = 0, plan_NCH = 0, plan_D = 0, plan_T = 0;
     int opt_depth = 0, opt_ablate = 0, opt_stamps = 0;
+    bool plan_tabu_fits = true;   // the tabu variants' extra n + 32 LDS bytes fit beside the rows
     unsigned long long *d_stamps = nullptr;
     size_t plan_lds = 0;
 
@@ -2297,7 +2309,7 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
     HIP_TRY(hipMalloc(&S.partial, T * (size_t)S.pstride * sizeof(Partial)));
     HIP_TRY(hipMalloc(&ctx->d_starts, T * 4));
     HIP_TRY(hipMalloc(&ctx->d_caps, T * 4));
-    HIP_TRY(hipMalloc(&ctx->d_tabu_list, N * 4));
+    HIP_TRY(hipMalloc(&ctx->d_tabu_list, (N + 64) * 4));   // + slack: the sweeps read it with 16-byte vectors up to ld
     HIP_TRY(hipMalloc(&ctx->d_best_succ, N * 4));
     HIP_TRY(hipMalloc(&ctx->d_tabu, sizeof(TabuState)));
     HIP_TRY(hipHostMalloc(&ctx->h_status, T * 4 * 2));
@@ -2529,7 +2541,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         const void *fn = kernel == 3 ? res_kernel(ctx->elem, nch, tabu)
                        : kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
         if (!fn) return fail(ctx, E_INTERNAL, "no kernel instance for nch=%d", nch);
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
+        const size_t need = tabu && kernel != 1 ? ((ctx->plan_lds + 15) & ~(size_t)15) + n + 32 : ctx->plan_lds;
+        if (tabu) ctx->plan_tabu_fits = need <= ctx->lds_max;      // plain 2-opt must not fail for the tabu variant's sake
+        if (need > ctx->lds_max) continue;
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)need));
     }
     return E_OK;
 }
@@ -2567,8 +2582,13 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
     }
     const void *fn = ctx->plan_kernel == 3 ? res_kernel(ctx->elem, ctx->plan_NCH, tabu)
                    : ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
+    // tabu: n + 32 verdict bytes behind everything else in the dynamic LDS
+    if (tabu && ctx->plan_kernel != 1 && !ctx->plan_tabu_fits)
+        return fail(ctx, E_EXHAUSTED, "tabu sweep: the rows leave no room for %d verdict bytes in LDS (use TSPGPU_OPT_KERNEL=1 or the matrix-free mode)", ctx->n + 32);
+    A.tabu_lds = (int)((ctx->plan_lds + 15) & ~(size_t)15);
+    const size_t lds = tabu && ctx->plan_kernel != 1 ? (size_t)A.tabu_lds + ctx->n + 32 : ctx->plan_lds;
     void *args[] = {&A};
-    HIP_TRY(hipLaunchKernel(fn, dim3(G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
+    HIP_TRY(hipLaunchKernel(fn, dim3(G, ntours), dim3(ctx->plan_BT), args, lds, ctx->stream));
     return E_OK;
 }
 
