@@ -108,6 +108,7 @@ def main():
     ap.add_argument("--cpu-sweeps", type=int, default=300, help="bounded CPU baseline sample (0 = skip)")
     ap.add_argument("--batch-starts", type=int, default=64, help="starts of the batched multi-start leg (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
+    ap.add_argument("--no-sizes", action="store_true", help="skip the n=1024 / n=16384 rows of the throughput table")
     args = ap.parse_args()
 
     import torch

@@ -57,8 +57,10 @@ enum {
     TSPGPU_OPT_DEPTH = 10,      /* matrix rows in flight per workgroup in the pipelined sweep (0 = auto) */
     TSPGPU_OPT_FUSED = 12,      /* one launch per sweep (resident kernel): 1 (default) when <= 4 tours are in flight,
                                    2 always, 0 never (separate sweep + apply launches) */
-    TSPGPU_OPT_MATRIX_FREE = 11 /* 0 auto (matrix-free when a matrix row cannot sit in LDS), 1 always, 2 never;
+    TSPGPU_OPT_MATRIX_FREE = 11,/* 0 auto (matrix-free when a matrix row cannot sit in LDS), 1 always, 2 never;
                                    takes effect at the next tspgpu_build_costs */
+    TSPGPU_OPT_SWEEP_CAP = 13   /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
+                                   reference's behaviour; >= 0 caps every local search: tests and bounded runs) */
 };
 
 int  tspgpu_device_count(void);

@@ -355,6 +355,54 @@ def test_d18512_five_sweeps(eng, T, O, golden):
     assert (sweeps, cost, fx(O, succ)) == (5, g["final_cost"], g["final_fnv"])
 
 
+def test_d18512_batched_multistart_capped_golden(eng, T, O):
+    """BASELINE config 4's instance through the path config 4 uses at that size -- the BATCHED multi-start
+    (more than 4 tours in flight: k_sweep_pipe + k_apply, not the one-launch-per-sweep kernel): NN + 5 sweeps
+    from starts 0..7 against the reference's own results (tests/golden/golden_d18512_multistart.json)"""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_d18512_multistart.json")))
+    xy, _ = O.read_tsplib(data_path("d18512"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_FUSED, 1)
+    eng.set_points(xy); eng.build_costs()
+    eng.set_option(T.OPT_SWEEP_CAP, g["max_sweeps"])
+    try:
+        starts = np.array([e["start"] for e in g["starts"]], dtype=np.int32)
+        res = eng.multistart_nn_2opt(starts, want_last=True)
+    finally:
+        eng.set_option(T.OPT_SWEEP_CAP, -1)
+    assert res["rc"] == 0 and res["sweeps"] == sum(e["sweeps"] for e in g["starts"])
+    assert (res["cost"], res["start"], fx(O, res["path"])) == (g["best"]["cost"], g["best"]["start"], g["best"]["fnv"])
+    assert (res["last_cost"], fx(O, res["last_path"])) == (g["starts"][-1]["cost"], g["starts"][-1]["fnv"])
+    for i, e in enumerate(g["starts"]):      # every start's tour is still in its slot
+        succ, cost, _ = eng.tour_store(i)
+        assert (cost, fx(O, succ)) == (e["cost"], e["fnv"]), e["start"]
+    info = eng.info()
+    assert info["kernel"] == 2 and info["matrix_free"] == 0
+
+
+def test_d18512_batched_multistart_local_optimum_certificate(eng, T, O):
+    """the same batch run to convergence (8 starts, ~19 000 sweeps; the reference needs hours): checked with
+    the ORACLE, not the engine -- the winner is a valid tour, its cost is the node-order recomputation, it is
+    the cheapest of the batch, and one full oracle sweep finds no improving move (2-opt local optimum)"""
+    xy, _ = O.read_tsplib(data_path("d18512"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_FUSED, 1)
+    eng.set_points(xy); eng.build_costs()
+    starts = np.arange(8, dtype=np.int32)
+    res = eng.multistart_nn_2opt(starts)
+    assert res["rc"] == 0 and eng.info()["kernel"] == 2
+    best = res["path"]
+    assert O.valid_tour(best) and O.tour_cost_xy(xy, O.EUC_2D, best) == res["cost"]
+    costs = []
+    for i in range(len(starts)):
+        succ, cost, last_delta = eng.tour_store(i)
+        assert O.valid_tour(succ) and O.tour_cost_xy(xy, O.EUC_2D, succ) == cost and last_delta >= -1e-7
+        costs.append(cost)
+    assert res["cost"] == min(costs) and res["start"] == int(np.argmin(costs))
+    probe = best.copy()
+    d, _, mv = O.two_opt_once_xy(xy, O.EUC_2D, probe, res["cost"])
+    assert d >= -1e-7 and np.array_equal(probe, best), (d, mv)
+
+
 def test_graph_and_eager_agree(eng, T, O, instances):
     xy, c = setup(eng, T, O, instances, "pr1002", 0)
     out = []
@@ -482,14 +530,111 @@ def test_multistart_subset_and_chunks(eng, T, O, instances):
     eng.set_option(T.OPT_FUSED, 1)
 
 
-def test_deadline_returns_code_4_with_valid_tour(eng, T, O, instances):
+@pytest.mark.parametrize("fused_mode", [1, 0])
+def test_deadline_returns_code_4_with_consistent_state(eng, T, O, instances, fused_mode):
+    """the cooperative deadline of ref_2opt (refinment.c:17-24: polled before every sweep): what comes back --
+    tour, cost, sweep count, move history -- is ONE state: every sweep that ran is applied, the history has
+    exactly `sweeps` moves, and cost = NN cost + the sum of their deltas = the oracle's after the same number
+    of sweeps"""
     xy, c = setup(eng, T, O, instances, "pr1002", 0)
-    eng.set_option(T.OPT_BATCH, 1)
-    succ, nn_cost = eng.nn_tour(0)
-    cost, sweeps, rc = eng.two_opt(succ, time_left_s=0.0)
-    eng.set_option(T.OPT_BATCH, 32)
-    assert rc == 4 and 1 <= sweeps < 169
-    assert O.valid_tour(succ) and O.tour_cost(c, succ) == cost and cost < nn_cost
+    eng.set_option(T.OPT_FUSED, fused_mode)
+    eng.set_option(T.OPT_HISTORY, 512)
+    try:
+        seen = set()
+        for left in (0.0, 0.0004, 0.0012, 0.003):
+            succ, nn_cost = eng.nn_tour(0)
+            cost, sweeps, rc = eng.two_opt(succ, time_left_s=left)
+            assert O.valid_tour(succ) and O.tour_cost(c, succ) == cost
+            if left == 0.0:
+                assert rc == 4 and sweeps == 0 and cost == nn_cost       # the deadline had passed: not one sweep
+                continue
+            assert rc in (0, 4) and 0 <= sweeps <= 169
+            a, b, d = eng.history(512)
+            if rc == 4:
+                assert len(a) == sweeps                                     # no sweep without its move, no move without its sweep
+                assert cost == nn_cost + float(np.sum(d[:sweeps]))
+                osucc, _ = O.nn_tour(c, 0)
+                osw, ocost = O.two_opt(c, osucc, sweeps) if sweeps else (0, nn_cost)
+                assert (osw, ocost) == (sweeps, cost) and np.array_equal(osucc, succ)
+            else:
+                assert sweeps == 169
+            seen.add(rc)
+        assert 4 in seen
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0)
+        eng.set_option(T.OPT_FUSED, 1)
+
+
+def test_multistart_last_tour_under_deadline(eng, T, O, instances):
+    """h_Greedy_2opt_mod_costs leaves the tour of the LAST start it processed in *solution, deadline or not
+    (heuristics.c:118-149; its caller posts that tour to CPLEX, cplex_model.c:1217-1243): with the starts in
+    chunks of 3 and the deadline striking in the first chunk, last_path is that chunk's last tour -- valid,
+    with its own cost"""
+    xy, c = setup(eng, T, O, instances, "n200_s3", 0)
+    eng.set_option(T.OPT_MAX_TOURS, 3)
+    try:
+        for left in (0.0, 0.0005):
+            res = eng.multistart_nn_2opt(np.arange(20, dtype=np.int32), time_left_s=left, want_last=True)
+            assert res["rc"] == 4
+            assert O.valid_tour(res["last_path"]) and O.tour_cost(c, res["last_path"]) == res["last_cost"]
+            assert O.valid_tour(res["path"]) and O.tour_cost(c, res["path"]) == res["cost"]
+            assert 0 <= res["start"] < 20 and res["cost"] <= res["last_cost"]
+            if left == 0.0:
+                assert res["start"] <= 2 and res["sweeps"] == 0          # first chunk, not one sweep
+        full = eng.multistart_nn_2opt(np.arange(20, dtype=np.int32), want_last=True)
+        want = O.multistart_nn_2opt(c, np.arange(20, dtype=np.int32))
+        assert full["rc"] == 0 and (full["cost"], full["start"]) == (want[1], want[2])
+        last, _ = O.nn_tour(c, 19)
+        _, lcost = O.two_opt(c, last)
+        assert full["last_cost"] == lcost and np.array_equal(full["last_path"], last)
+    finally:
+        eng.set_option(T.OPT_MAX_TOURS, 1024)
+
+
+def test_slots_survive_growth_and_empty_slots_fail(eng, T, O, instances):
+    """tour slots: growing the slot array keeps what the existing slots hold; a slot that was never loaded
+    answers FAILED_PRECONDITION (9) instead of sweeping over uninitialised arrays; a new matrix empties them"""
+    xy, c = setup(eng, T, O, instances, "kroA100", 0)
+    succ, cost = O.nn_tour(c, 3)
+    eng.tour_load(0, succ)
+    eng.tour_nn(40, 7)                       # beyond the initial 16 slots: the array grows
+    g, gcost, _ = eng.tour_store(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    sw, _ = eng.tour_two_opt(0)
+    osw, ocost = O.two_opt(c, succ)
+    g, gcost, _ = eng.tour_store(0)
+    assert (sw, gcost) == (osw, ocost) and np.array_equal(g, succ)
+    for call in (lambda: eng.tour_two_opt(5), lambda: eng.tour_store(5), lambda: eng.tour_copy(6, 5),
+                 lambda: eng.tour_sweep_part(5, 0, 1), lambda: eng.time_sweep(5, 1)):
+        with pytest.raises(T.TspGpuError) as ei:
+            call()
+        assert ei.value.code == 9
+    eng.tour_copy(5, 40)
+    o7, c7 = O.nn_tour(c, 7)
+    g, gcost, _ = eng.tour_store(5)
+    assert gcost == c7 and np.array_equal(g, o7)
+    eng.build_costs()                        # a new matrix: the slots' edge costs are stale
+    with pytest.raises(T.TspGpuError) as ei:
+        eng.tour_two_opt(0)
+    assert ei.value.code == 9
+
+
+def test_nn_on_disconnected_matrix_fails_loudly(eng, T, O):
+    """NOT_CONNECTED (-1) off the diagonal of a caller matrix can leave NN without an admissible edge: the
+    reference closes the path early and ends with an invalid tour (heuristics.c:266-272); here the call fails"""
+    n = 40
+    rng = np.random.default_rng(3)
+    c = rng.integers(1, 500, size=(n, n)).astype(np.float64)
+    c = np.triu(c, 1); c = c + c.T
+    np.fill_diagonal(c, -1.0)
+    c[:, 17] = -1.0; c[17, :] = -1.0         # node 17 unreachable
+    for elem in (0, 1):
+        eng.set_option(T.OPT_ELEM, elem)
+        eng.set_costs(np.ascontiguousarray(c))
+        with pytest.raises(T.TspGpuError) as ei:
+            eng.nn_tour(0)
+        assert ei.value.code == 3 and "incomplete" in str(ei.value)
+    eng.set_option(T.OPT_ELEM, 0)
 
 
 # ------------------------------------------------------------------ K3 tabu

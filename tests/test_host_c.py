@@ -204,3 +204,67 @@ def test_bench_line_contract():
     assert d["final_cost_rank0"] == 488522.0 and d["config"]["sweeps_per_step_rank0"] == 609
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def _mod_costs_matrix(c, seed):
+    """c[i][j] * (1 - x*_ij), symmetric, diagonal 0: the matrix cplex_model.c:1176-1258 builds per callback
+    (same construction as oracle/make_golden_slow.py mod_costs_threads)"""
+    import numpy as np
+    n = c.shape[0]
+    r = np.random.default_rng(seed)
+    x = np.triu(r.random((n, n)), 1)
+    x = x + x.T
+    mc = c * (1.0 - x)
+    np.fill_diagonal(mc, 0.0)
+    return np.ascontiguousarray(mc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kroA100", "n200_s3"])
+def test_mod_costs_concurrent_threads(host, O, instances, name):
+    """h_Greedy_2opt_mod_costs is the one entry point of the path that CPLEX enters from several worker
+    threads at once, each with its own matrix and solution (cplex_model.c:1176-1258, <= 32 threads,
+    cplex_model.h:12).  Four threads through libtsphost.so (ctypes drops the GIL), two rounds with the SAME
+    buffers refilled in between (a pointer says nothing about the contents): every result equals the
+    reference's for that matrix bit for bit, and a thread's device context dies with the thread."""
+    import json
+    import threading
+    import numpy as np
+    g = [c for c in json.load(open(os.path.join(ROOT, "tests", "golden", "golden_mod_costs_threads.json")))["cases"]
+         if c["instance"] == name]
+    assert len(g) == 4
+    c = instances(name)[1]
+    n = c.shape[0]
+    host.tsp_init()
+    host.err_setverbosity(0)
+    inst = Instance.in_dll(host, "tsp_inst")
+    env = Options.in_dll(host, "tsp_env")
+    inst.nnodes = n
+    env.timelimit = -1.0
+    host.utils_startclock(C.byref(inst, Instance.c.offset))
+    host.h_Greedy_2opt_mod_costs.argtypes = [C.POINTER(Solution), C.c_void_p]
+    host.tsp_gpu_thread_contexts.restype = C.c_int
+    bufs = [np.empty((n, n), dtype=np.float64) for _ in g]          # one caller buffer per thread, reused
+    out = {}
+
+    def work(slot, case):
+        bufs[slot][:] = _mod_costs_matrix(c, case["seed"])
+        path = (C.c_int * n)()
+        sol = Solution(0.0, C.cast(path, C.POINTER(C.c_int)), 0, None)
+        rc = host.h_Greedy_2opt_mod_costs(C.byref(sol), bufs[slot].ctypes.data)
+        out[(slot, case["seed"])] = (rc, sol.cost, np.array(path[:], dtype=np.int32), host.tsp_gpu_thread_contexts())
+
+    for rnd in range(2):
+        order = g if rnd == 0 else g[1:] + g[:1]                     # round 2: every buffer gets another matrix
+        ts = [threading.Thread(target=work, args=(i, case)) for i, case in enumerate(order)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for i, case in enumerate(order):
+            rc, cost, path, live = out[(i, case["seed"])]
+            assert rc == 0 and 1 <= live <= 4
+            assert float(cost).hex() == case["cost_hex"], (rnd, case, cost)
+            assert "%016x" % O.fnv1a(path) == case["fnv"]
+        assert host.tsp_gpu_thread_contexts() == 0                   # destroyed at thread exit
+    host.tsp_gpu_release()

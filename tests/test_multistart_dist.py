@@ -167,3 +167,102 @@ def test_sharded_sweep_two_ranks_one_gpu(name, matrix_free, cap):
     for rank, sweeps, cost, fnv, kernel in out:
         assert (sweeps, cost, "%016x" % fnv) == (cap if cap > 0 else g["sweeps"], g["final_cost"], g["final_fnv"]), out
         assert (kernel == 4) == matrix_free
+
+
+# ---------------------------------------------------------------------------
+# the sharded multi-start with the PRODUCT as the per-rank solver: two ranks share the one GPU of the
+# test box (gloo for the key exchange), each runs Engine.multistart_nn_2opt on its share of the starts
+# (start i -> rank i mod 2); the result must be the sequential h_greedy_2opt one (golden, reference)
+# ---------------------------------------------------------------------------
+def _engine_worker(rank, world, port, name, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle as O
+    import travellingsalesmanoptimization_amd as T
+    from travellingsalesmanoptimization_amd import multistart
+    xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", name + ".tsp"))
+    n = len(xy)
+    eng = T.Engine(0)
+    eng.set_points(xy); eng.build_costs()
+    calls = []
+
+    def solve_local(starts):
+        calls.append(len(starts))
+        return eng.multistart_nn_2opt(starts)          # the HIP engine, through the C ABI
+
+    res = multistart.multistart_nn_2opt(solve_local, np.arange(n, dtype=np.int32), n=n)
+    q.put((rank, res["cost"], res["start"], res["sweeps"], O.fnv1a(res["path"]), bool(O.valid_tour(res["path"])), calls))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["kroA100", "pr1002"])
+def test_sharded_multistart_engine_two_ranks_one_gpu(name):
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["algs"][name + "_2opt_greedy"]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_engine_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n = {"kroA100": 100, "pr1002": 1002}[name]
+    for rank, cost, start, sweeps, fnv, valid, calls in out:
+        assert (cost, "%016x" % fnv) == (g["cost"], g["fnv"]) and valid, out
+        assert calls == [len(range(rank, n, world))]       # each rank solved exactly its own share, once
+    assert out[0][1:5] == out[1][1:5]
+
+
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)       # "nccl" IS RCCL on ROCm
+    import oracle as O
+    import travellingsalesmanoptimization_amd as T
+    from travellingsalesmanoptimization_amd import multistart
+    xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", "kroA100.tsp"))
+    eng = T.Engine(0)
+    eng.set_points(xy); eng.build_costs()
+    res = eng.multistart_nn_2opt()
+    dev = torch.device("cuda", 0)
+    # integer costs: all_reduce(MIN, int64) + broadcast; non-integer: all_reduce + all_gather + broadcast
+    c1, s1, p1 = multistart.select_best(res["cost"], res["start"], res["path"], device=dev, force=True)
+    c2, s2, p2 = multistart.select_best(res["cost"] + 0.25, res["start"], res["path"], device=dev, force=True)
+    torch.cuda.synchronize()
+    q.put((res["cost"], res["start"], O.fnv1a(res["path"]), c1, s1, O.fnv1a(p1), c2, s2, O.fnv1a(p2), dist.get_backend()))
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_rccl_executes_the_exchange_on_one_rank():
+    """the collective of the sharded multi-start, executed by RCCL itself: a 1-rank "nccl" process group on the
+    MI355X, select_best forced through all_reduce(MIN, int64) + broadcast (and the all-gather variant of the
+    float-cost path) next to a live engine context on the same GPU"""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["algs"]["kroA100_2opt_greedy"]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    out = q.get(timeout=300)
+    p.join(60)
+    assert p.exitcode == 0
+    cost, start, fnv, c1, s1, f1, c2, s2, f2, backend = out
+    assert backend == "nccl"
+    assert (cost, "%016x" % fnv) == (g["cost"], g["fnv"])
+    assert (c1, s1, f1) == (cost, start, fnv)
+    assert (c2, s2, f2) == (cost + 0.25, start, fnv)

@@ -393,6 +393,7 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
                                              const int *__restrict__ starts, const double2 *__restrict__ pts, int kind)
 {
     __shared__ Partial red[2][16];
+    __shared__ int fill_pos;
     const int t = slot0 + blockIdx.x;
     const int start = starts[blockIdx.x];
     int *ord = S.ord + (size_t)t * n;
@@ -434,6 +435,16 @@ __global__ void __launch_bounds__(1024) k_nn(Tours S, const T *__restrict__ mat,
         if (tid == 0) { ord[step] = nxt; total += lo; }
         cur = nxt;
     }
+    if (step < n) {
+        // Some node has no admissible edge left (NOT_CONNECTED entries of a caller matrix): the reference closes
+        // the path early (heuristics.c:266-272) and ends with an invalid tour, which tsp_update_best_solution
+        // rejects.  Here the remaining cells take the unvisited nodes so that ord[] stays a permutation (no
+        // kernel ever gathers through garbage) and status 1 makes the host fail the call.
+        if (tid == 0) fill_pos = step;
+        __syncthreads();
+        for (int k = 0, i = tid; i < n; i += BT, k++)
+            if (!((k < 64 ? seen >> k : seen_hi >> (k - 64)) & 1)) ord[atomicAdd(&fill_pos, 1)] = i;
+    }
     if (tid == 0) {
         total += mat ? Elem<T>::widen(mat[(size_t)cur * ld + start]) : (double)cell<T>(mat, pts, kind, ld, cur, start); // heuristics.c:281
         S.cost[t] = total;
@@ -458,6 +469,7 @@ __global__ void __launch_bounds__(1024) k_nn_vec(Tours S, const T *__restrict__ 
     constexpr int V = Elem<T>::V;
     constexpr bool INT = !std::is_same<T, double>::value;
     __shared__ Partial red[2][16];
+    __shared__ int fill_pos;
     const int t = slot0 + blockIdx.x;
     const int start = starts[blockIdx.x];
     int *ord = S.ord + (size_t)t * n;
@@ -523,6 +535,18 @@ __global__ void __launch_bounds__(1024) k_nn_vec(Tours S, const T *__restrict__ 
         mark(nxt);
         if (tid == 0) { ord[step] = nxt; total += lo; }
         cur = nxt;
+    }
+    if (step < n) {   // incomplete tour: see k_nn
+        if (tid == 0) fill_pos = step;
+        __syncthreads();
+        for (int c = 0; c < nch; c++) {
+            const int vi = c * BT + tid;
+            const u64 bits = (c * V < 64 ? seen >> (c * V) : seen_hi >> (c * V - 64));
+            for (int v = 0; v < V; v++) {
+                const int i = vi * V + v;
+                if (vi < nvec && i < n && !((bits >> v) & 1)) ord[atomicAdd(&fill_pos, 1)] = i;
+            }
+        }
     }
     if (tid == 0) {
         total += Elem<T>::widen(mat[(size_t)cur * ld + start]); // heuristics.c:281
@@ -2162,6 +2186,14 @@ __global__ void k_rearm(Tours S, int slot0, int count, int cap)
     if (i < count) { S.done[slot0 + i] = 0; S.nsweeps[slot0 + i] = 0; S.cap_sweeps[slot0 + i] = cap; }
 }
 
+// deadline drain of the one-launch-per-sweep path: the sweep cap of every unfinished tour := the sweeps it has
+// completed, so that the next launch applies the pending move and stops (refinment.c:17-26: a sweep that ran is applied)
+__global__ void k_cap_now(Tours S, int slot0, int count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count && !S.done[slot0 + i]) S.cap_sweeps[slot0 + i] = S.nsweeps[slot0 + i];
+}
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -2176,11 +2208,12 @@ struct tspgpu_ctx {
 
     // options
     int opt_elem = TSPGPU_ELEM_AUTO, opt_kernel = 0, opt_batch = 32, opt_wgs = 0, opt_hist = 0, opt_graph = 1,
-        opt_timing = 0, opt_block = 0, opt_max_tours = 1024;
+        opt_timing = 0, opt_block = 0, opt_max_tours = 1024, opt_sweep_cap = -1;
 
     // instance
     int n = 0, ld = 0, kind = TSPGPU_EUC_2D;
     bool have_points = false, have_costs = false, symmetric = true;
+    bool built = false;      // the matrix (or the matrix-free mode) comes from tspgpu_build_costs, not from a caller
     int elem = 0; // TSPGPU_ELEM_F64 / _I32 / _U16 in use
     double2 *d_pts = nullptr;
     void *d_mat = nullptr;   // [n][ld] cells of the kind in `elem`; nullptr in matrix-free mode
@@ -2194,6 +2227,7 @@ struct tspgpu_ctx {
     // tours
     int tcap = 0;
     Tours S{};
+    std::vector<unsigned char> slot_valid;   // [tcap] host side: the slot holds a complete tour state
     int *d_starts = nullptr, *d_caps = nullptr;
     int *h_status = nullptr; // pinned: done[tcap] then nsweeps[tcap]
     double *h_costs = nullptr; // pinned [tcap]
@@ -2249,54 +2283,74 @@ static void free_matrix(tspgpu_ctx *ctx)
 {
     if (ctx->d_mat) hipFree(ctx->d_mat);
     ctx->d_mat = nullptr; ctx->have_costs = false;
+    std::fill(ctx->slot_valid.begin(), ctx->slot_valid.end(), 0);   // the slots' edge costs belong to the old matrix
     drop_graphs(ctx);
+}
+
+static void free_fused(tspgpu_ctx *ctx)
+{
+    Fused &F = ctx->F;
+    for (int p = 0; p < 2; p++) {
+        void *fp[] = {F.ord[p], F.pos[p], F.nl[p], F.nr[p], F.dl[p], F.dr[p], F.dir[p], F.k[p], F.stop[p], F.cost[p], F.partial[p]};
+        for (void *q : fp) if (q) hipFree(q);
+    }
+    if (F.cur) hipFree(F.cur);
+    if (F.bestkey) hipFree(F.bestkey);
+    for (int p = 0; p < 2; p++) if (F.payload[p]) hipFree(F.payload[p]);
+    memset(&F, 0, sizeof F);
+    ctx->fcap = 0;
+}
+
+static void free_tour_arrays(Tours &S)
+{
+    void *ptrs[] = {S.ord, S.pos, S.succ, S.dpos, S.dnb, S.cost, S.last_delta, S.dir, S.done, S.nsweeps, S.cap_sweeps, S.status, S.partial};
+    for (void *p : ptrs) if (p) hipFree(p);
+    memset(&S, 0, sizeof S);
+}
+
+// per-capacity scratch next to the slots (start lists, pinned status words)
+static void free_tour_scratch(tspgpu_ctx *ctx)
+{
+    if (ctx->d_starts) hipFree(ctx->d_starts);
+    if (ctx->d_caps) hipFree(ctx->d_caps);
+    if (ctx->h_status) hipHostFree(ctx->h_status);
+    if (ctx->h_costs) hipHostFree(ctx->h_costs);
+    ctx->d_starts = ctx->d_caps = nullptr; ctx->h_status = nullptr; ctx->h_costs = nullptr;
 }
 
 static void free_tours(tspgpu_ctx *ctx)
 {
-    Tours &S = ctx->S;
-    void *ptrs[] = {S.ord, S.pos, S.succ, S.dpos, S.dnb, S.cost, S.last_delta, S.dir, S.done, S.nsweeps, S.cap_sweeps, S.status,
-                    S.partial, ctx->d_starts, ctx->d_caps, ctx->d_tabu_list, ctx->d_best_succ, ctx->d_tabu};
+    free_tour_arrays(ctx->S);
+    free_tour_scratch(ctx);
+    void *ptrs[] = {ctx->d_tabu_list, ctx->d_best_succ, ctx->d_tabu};
     for (void *p : ptrs) if (p) hipFree(p);
-    if (ctx->h_status) hipHostFree(ctx->h_status);
-    if (ctx->h_costs) hipHostFree(ctx->h_costs);
-    {
-        Fused &F = ctx->F;
-        for (int p = 0; p < 2; p++) {
-            void *fp[] = {F.ord[p], F.pos[p], F.nl[p], F.nr[p], F.dl[p], F.dr[p], F.dir[p], F.k[p], F.stop[p], F.cost[p], F.partial[p]};
-            for (void *q : fp) if (q) hipFree(q);
-        }
-        if (F.cur) hipFree(F.cur);
-        if (F.bestkey) hipFree(F.bestkey);
-        for (int p = 0; p < 2; p++) if (F.payload[p]) hipFree(F.payload[p]);
-        memset(&F, 0, sizeof F);
-        ctx->fcap = 0;
-    }
-    memset(&S, 0, sizeof S);
-    ctx->d_starts = ctx->d_caps = ctx->d_tabu_list = ctx->d_best_succ = nullptr;
-    ctx->d_tabu = nullptr; ctx->h_status = nullptr; ctx->h_costs = nullptr; ctx->tcap = 0;
+    ctx->d_tabu_list = ctx->d_best_succ = nullptr; ctx->d_tabu = nullptr;
+    free_fused(ctx);
+    ctx->tcap = 0;
+    ctx->slot_valid.clear();
     drop_graphs(ctx);
 }
 
+// Tour slots [0, want).  Growing keeps the contents of the slots that exist (a tour loaded into slot 0 survives a
+// later tspgpu_tour_nn(20) or a multi-start); new slots are zero-filled and marked invalid until something is
+// loaded / built / copied into them (slot_valid: the slot entry points answer FAILED_PRECONDITION otherwise).
 static int ensure_tours(tspgpu_ctx *ctx, int want)
 {
     if (want <= ctx->tcap) return E_OK;
-    want = std::max(want, 16); // growing re-allocates and invalidates every slot: start roomy
+    want = std::max(want, 16);
     const int n = ctx->n;
-    if (ctx->tcap) {
-        // grow: keep it simple, slots are scratch between public calls
-        free_tours(ctx);
-    }
-    const size_t T = (size_t)want, N = (size_t)n;
-    Tours &S = ctx->S;
+    const size_t T = (size_t)want, N = (size_t)n, O = (size_t)ctx->tcap;
+    Tours S{};
     const size_t slack = 64; // vector reads of the last tour's tail (load_run)
     HIP_TRY(hipMalloc(&S.ord, (T * N + slack) * 4));
     HIP_TRY(hipMalloc(&S.pos, (T * N + slack) * 4));
     HIP_TRY(hipMalloc(&S.succ, (T * N + slack) * 4));
     HIP_TRY(hipMalloc(&S.dpos, (T * N + slack) * 8));
     HIP_TRY(hipMalloc(&S.dnb, (T * N + slack) * 8));
+    HIP_TRY(hipMemsetAsync(S.ord, 0, (T * N + slack) * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.pos, 0, (T * N + slack) * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.succ, 0, (T * N + slack) * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.dpos, 0, (T * N + slack) * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.dnb, 0, (T * N + slack) * 8, ctx->stream));
     HIP_TRY(hipMalloc(&S.dir, T * 4));
     HIP_TRY(hipMalloc(&S.cost, T * 8));
@@ -2305,19 +2359,61 @@ static int ensure_tours(tspgpu_ctx *ctx, int want)
     HIP_TRY(hipMalloc(&S.nsweeps, T * 4));
     HIP_TRY(hipMalloc(&S.cap_sweeps, T * 4));
     HIP_TRY(hipMalloc(&S.status, T * 4));
-    S.pstride = std::max(MAX_WGS_PER_TOUR, (n + 7) / 8 + 8); // the matrix-free sweep runs n/8 workgroups per tour
-    HIP_TRY(hipMalloc(&S.partial, T * (size_t)S.pstride * sizeof(Partial)));
-    HIP_TRY(hipMalloc(&ctx->d_starts, T * 4));
-    HIP_TRY(hipMalloc(&ctx->d_caps, T * 4));
-    HIP_TRY(hipMalloc(&ctx->d_tabu_list, (N + 64) * 4));   // + slack: the sweeps read it with 16-byte vectors up to ld
-    HIP_TRY(hipMalloc(&ctx->d_best_succ, N * 4));
-    HIP_TRY(hipMalloc(&ctx->d_tabu, sizeof(TabuState)));
-    HIP_TRY(hipHostMalloc(&ctx->h_status, T * 4 * 2));
-    HIP_TRY(hipHostMalloc(&ctx->h_costs, T * 8));
+    HIP_TRY(hipMemsetAsync(S.dir, 0, T * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.cost, 0, T * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.last_delta, 0, T * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.done, 0, T * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.nsweeps, 0, T * 4, ctx->stream));
+    HIP_TRY(hipMemsetAsync(S.cap_sweeps, 0xff, T * 4, ctx->stream));
     HIP_TRY(hipMemsetAsync(S.status, 0, T * 4, ctx->stream));
+    S.pstride = std::max(MAX_WGS_PER_TOUR, (n + 7) / 8 + 8); // the matrix-free sweep runs n/8 workgroups per tour
+    HIP_TRY(hipMalloc(&S.partial, T * (size_t)S.pstride * sizeof(Partial)));
+    if (O) {
+        const Tours &P = ctx->S;
+        const hipMemcpyKind dd = hipMemcpyDeviceToDevice;
+        HIP_TRY(hipMemcpyAsync(S.ord, P.ord, O * N * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.pos, P.pos, O * N * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.succ, P.succ, O * N * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.dpos, P.dpos, O * N * 8, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.dnb, P.dnb, O * N * 8, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.dir, P.dir, O * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.cost, P.cost, O * 8, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.last_delta, P.last_delta, O * 8, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.done, P.done, O * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.nsweeps, P.nsweeps, O * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.cap_sweeps, P.cap_sweeps, O * 4, dd, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(S.status, P.status, O * 4, dd, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        free_tour_arrays(ctx->S);
+        free_tour_scratch(ctx);
+        free_fused(ctx);          // sized by the slot count; only live inside a run
+        drop_graphs(ctx);         // captured launches hold the old pointers
+    }
+    ctx->S = S;
+    HIP_TRY(hipMalloc(&ctx->d_starts, T * 4));
+    HIP_TRY(hipMalloc(&ctx->d_caps, T * 4));
+    if (!ctx->d_tabu_list) {
+        HIP_TRY(hipMalloc(&ctx->d_tabu_list, (N + 64) * 4));   // + slack: the sweeps read it with 16-byte vectors up to ld
+        HIP_TRY(hipMalloc(&ctx->d_best_succ, N * 4));
+        HIP_TRY(hipMalloc(&ctx->d_tabu, sizeof(TabuState)));
+    }
+    HIP_TRY(hipHostMalloc(&ctx->h_status, T * 4 * 2));
+    HIP_TRY(hipHostMalloc(&ctx->h_costs, T * 8));
     ctx->tcap = want;
+    ctx->slot_valid.resize(T, 0);
+    return E_OK;
+}
+
+static void mark_slots(tspgpu_ctx *ctx, int slot0, int count, bool valid)
+{
+    for (int i = slot0; i < slot0 + count && i < (int)ctx->slot_valid.size(); i++) ctx->slot_valid[i] = valid ? 1 : 0;
+}
+
+// a slot entry point was handed `slot`: it must exist and hold a tour
+static int need_slot(tspgpu_ctx *ctx, int slot)
+{
+    if (slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "slot %d outside [0,%d)", slot, ctx->tcap);
+    if (!ctx->slot_valid[slot]) return fail(ctx, E_PRECOND, "slot %d holds no tour (load, build or copy one into it first)", slot);
     return E_OK;
 }
 
@@ -2676,8 +2772,22 @@ static int launch_fused(tspgpu_ctx *ctx, int slot0, int ntours, int parity)
     return E_OK;
 }
 
+// Rough duration of one sweep iteration over `ntours` tours before anything has been measured (rows at ~4 TB/s
+// plus the fixed launch chain): only used to decide how early the deadline logic leaves the batched mode.
+static double est_iter_s(const tspgpu_ctx *ctx, int ntours)
+{
+    const double n = ctx->n;
+    if (ctx->otf) return ntours * (20e-6 + n * n / 2 / 5e11);
+    return ntours * (12e-6 + n * ctx->ld * (double)elem_size(ctx->elem) / 4e12);
+}
+
 // One launch per sweep (k_sweep_fused): begin, batches of an even number of launches with
 // alternating parity (replayed as a hipGraph), end.
+//
+// Deadline (refinment.c:17-24 polls before every sweep): while more than three batches' worth of time is left the
+// batches run pipelined against the host; after that single launches, one host poll each; once the time is up the
+// sweep that already ran is applied (k_cap_now + two launches), so the tour, its cost, the sweep count and the move
+// history returned are those of one and the same state, at most one sweep past the deadline.
 static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s, bool *deadline_hit)
 {
     int rc = ensure_fused(ctx);
@@ -2686,14 +2796,24 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
     const bool f64 = ctx->elem == TSPGPU_ELEM_F64;
     const dim3 grid1((n + 255) / 256, ntours);
     const bool pk = ctx->elem == TSPGPU_ELEM_U16;
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; return E_OK; }   // not one sweep
     if (f64) hipLaunchKernelGGL((k_fused_begin<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
     else if (pk) hipLaunchKernelGGL((k_fused_begin<int, true>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
     else hipLaunchKernelGGL((k_fused_begin<int, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0);
     HIP_TRY(hipGetLastError());
-    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     const int K = std::max(2, ctx->opt_batch & ~1);
-    long issued = 0;
-    // one batch = K launches (a replayed hipGraph) + the copy of the `done` words
+    long issued = 0;      // launches so far; the next one writes parity issued & 1
+    bool late = false;
+    auto launch_eager = [&](int cnt) -> int {
+        for (int i = 0; i < cnt; i++) {
+            const int rc = launch_fused(ctx, slot0, ntours, (int)(issued & 1));
+            if (rc) return rc;
+            issued++;
+        }
+        return E_OK;
+    };
+    // one batch = K launches (a replayed hipGraph; `issued` is even whenever this runs) + the copy of the `done` words
     auto issue_batch = [&](int *h_done) -> int {
         int rc = E_OK;
         if (ctx->opt_graph) {
@@ -2712,10 +2832,8 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
                 ctx->graphs.push_back({slot0, ntours, 2, K, exec});
             }
             HIP_TRY(hipGraphLaunch(exec, ctx->stream));
-        } else {
-            for (int i = 0; i < K; i++)
-                if ((rc = launch_fused(ctx, slot0, ntours, i & 1))) return rc;
-        }
+            issued += K;
+        } else if ((rc = launch_eager(K))) return rc;
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_done, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
         return E_OK;
@@ -2724,7 +2842,32 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
         for (int i = 0; i < ntours; i++) if (!h_done[i]) return false;
         return true;
     };
-    if (!ctx->opt_timing) {
+    bool finished = false;
+    bool careful = t_end >= 0 && time_left_s < 3.0 * K * est_iter_s(ctx, ntours);
+    if (ctx->opt_timing) {
+        for (;;) {
+            // timing mode: one event pair around the whole batch (the launches of a batch run back to
+            // back, so batch time / K is the mean launch duration); only batches in which every launch
+            // swept are counted
+            while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            const long before = issued;
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+            if ((rc = issue_batch(ctx->h_status))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            {
+                int live = 0; // launches 0 .. nsweeps-1 swept (launch nsweeps only found the tour finished)
+                for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
+                if (before + K <= live) {
+                    float ms = 0;
+                    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+                    ctx->sweep_ms_total += ms; ctx->sweep_launches += K;
+                }
+            }
+            if (all_done(ctx->h_status)) { finished = true; break; }
+            if (t_end >= 0 && now_s() >= t_end) { late = true; break; }
+        }
+    } else if (!careful) {
         // Pipelined: the next batch is in the stream before the host looks at the previous one's
         // `done` words, so the device never waits for the host (a graph launch + a sync cost
         // ~20 us per batch otherwise); the price is one batch of immediately-returning launches
@@ -2733,45 +2876,56 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
         int *buf[2] = {ctx->h_status, ctx->h_status + ctx->tcap};
         if ((rc = issue_batch(buf[0]))) return rc;
         HIP_TRY(hipEventRecord(ctx->ev[2], ctx->stream));
+        double t_prev = now_s(), batch_dt = 0;
         for (int cur = 0;; cur ^= 1) {
             if ((rc = issue_batch(buf[cur ^ 1]))) return rc;
             HIP_TRY(hipEventRecord(ctx->ev[2 + (cur ^ 1)], ctx->stream));
             HIP_TRY(hipEventSynchronize(ctx->ev[2 + cur]));
-            if (all_done(buf[cur])) break;
-            if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
-        }
-    } else
-    for (;;) {
-        // timing mode: one event pair around the whole batch (the launches of a batch run back to
-        // back, so batch time / K is the mean launch duration); only batches in which every launch
-        // swept are counted
-        while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
-        HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
-        if ((rc = issue_batch(ctx->h_status))) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        {
-            int live = 0; // launches 0 .. nsweeps-1 swept (launch nsweeps only found the tour finished)
-            for (int i = 0; i < ntours; i++) live = std::max(live, ctx->h_status[ctx->tcap + i]);
-            if (issued + K <= live) {
-                float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-                ctx->sweep_ms_total += ms; ctx->sweep_launches += K;
+            if (all_done(buf[cur])) { finished = true; break; }
+            if (t_end >= 0) {
+                const double now = now_s();
+                batch_dt = batch_dt == 0 ? now - t_prev : 0.5 * (batch_dt + now - t_prev);
+                t_prev = now;
+                if (now >= t_end || t_end - now < 3.0 * batch_dt) {
+                    // leave the batched mode: wait for the batch in flight, then poll per launch
+                    HIP_TRY(hipEventSynchronize(ctx->ev[2 + (cur ^ 1)]));
+                    if (all_done(buf[cur ^ 1])) finished = true;
+                    careful = true;
+                    break;
+                }
             }
         }
-        issued += K;
-        if (all_done(ctx->h_status)) break;
-        if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
     }
-    if (f64) hipLaunchKernelGGL((k_fused_end<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
-    else if (pk) hipLaunchKernelGGL((k_fused_end<int, true>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
-    else hipLaunchKernelGGL((k_fused_end<int, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, 1);
+    if (careful && !finished && !late) {
+        for (;;) {
+            if (now_s() >= t_end) { late = true; break; }
+            if ((rc = launch_eager(1))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.done + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (all_done(ctx->h_status)) { finished = true; break; }
+        }
+    }
+    if (late) {
+        if (deadline_hit) *deadline_hit = true;
+        if (issued > 0) {
+            // apply the move of the last sweep that ran: cap := sweeps completed, then one launch applies it and raises
+            // `stop`, the next one raises `done` (a tour whose last sweep found nothing finishes the ordinary way)
+            hipLaunchKernelGGL(k_cap_now, dim3((ntours + 63) / 64), dim3(64), 0, ctx->stream, ctx->S, slot0, ntours);
+            HIP_TRY(hipGetLastError());
+            if ((rc = launch_eager(2))) return rc;
+        }
+    }
+    const int last_parity = (int)((issued + 1) & 1);   // parity written by the last launch (moot once `done` is up)
+    if (f64) hipLaunchKernelGGL((k_fused_end<double, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, last_parity);
+    else if (pk) hipLaunchKernelGGL((k_fused_end<int, true>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, last_parity);
+    else hipLaunchKernelGGL((k_fused_end<int, false>), grid1, dim3(256), 0, ctx->stream, ctx->S, ctx->F, n, slot0, last_parity);
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
 
 // Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
-// done, `max_iters` pairs were issued (tabu), or the deadline passed.
+// done, `max_iters` pairs were issued (tabu), or the deadline passed (checked before every batch; the batches
+// shrink to single iterations once fewer than three batches' worth of time is left, refinment.c:17-24).
 static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s,
                       bool *deadline_hit)
 {
@@ -2790,10 +2944,17 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     const int K = std::max(1, ctx->opt_batch);
     long issued = 0;
+    double iter_dt = est_iter_s(ctx, ntours);   // seconds per (sweep, apply) pair: estimate, then measured
     for (;;) {
         int todo = K;
         if (max_iters >= 0) todo = (int)std::min<long>(K, max_iters - issued);
         if (todo <= 0) break;
+        double t_batch = 0;
+        if (t_end >= 0) {
+            t_batch = now_s();
+            if (t_batch >= t_end) { if (deadline_hit) *deadline_hit = true; break; }
+            if (t_end - t_batch < 3.0 * K * iter_dt) todo = 1;
+        }
         const bool use_graph = ctx->opt_graph && !ctx->opt_timing && todo == K;
         if (use_graph) {
             hipGraphExec_t exec = nullptr;
@@ -2832,6 +2993,7 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
         if (ctx->opt_timing)
             HIP_TRY(hipMemcpyAsync(ctx->h_status + ctx->tcap, ctx->S.nsweeps + slot0, (size_t)ntours * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (t_end >= 0) iter_dt = (now_s() - t_batch) / todo;
         if (ctx->opt_timing) {
             // count only launches that did work: once every tour is done a sweep exits at once
             int live = 0;
@@ -2846,7 +3008,6 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
         bool all = true;
         for (int i = 0; i < ntours; i++) if (!ctx->h_status[i]) { all = false; break; }
         if (all) break;
-        if (t_end >= 0 && now_s() > t_end) { if (deadline_hit) *deadline_hit = true; break; }
     }
     return E_OK;
 }
@@ -2898,7 +3059,9 @@ static int load_path(tspgpu_ctx *ctx, int slot, const int *path, int cap)
     if (rc) return rc;
     HIP_TRY(hipMemcpyAsync(ctx->S.ord + (size_t)slot * ctx->n, ord.data(), (size_t)ctx->n * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return init_slots(ctx, slot, 1, cap);
+    if ((rc = init_slots(ctx, slot, 1, cap))) return rc;
+    mark_slots(ctx, slot, 1, true);
+    return E_OK;
 }
 
 static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
@@ -2911,13 +3074,19 @@ static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double
     return E_OK;
 }
 
+// NN tours from h_starts into ord[] / cost[] of slots [slot0, slot0+count).  The slots are NOT complete tour states
+// afterwards (init_slots derives pos / succ / edge costs); they are marked invalid here and valid again by the callers
+// that run init_slots.  Fails with INVALID_ARGUMENT when a tour could not be completed (an unvisited node without an
+// admissible edge: NOT_CONNECTED entries) -- the reference ends with an invalid tour there (heuristics.c:266-272).
 static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
 {
     const int n = ctx->n;
     for (int i = 0; i < count; i++)
         if (h_starts[i] < 0 || h_starts[i] >= n) return fail(ctx, E_UNAVAILABLE, "starting node %d not in [0,%d)", h_starts[i], n);
+    mark_slots(ctx, slot0, count, false);
     HIP_TRY(hipMemcpyAsync(ctx->d_starts, h_starts, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    bool launched = false;
     if (ctx->d_mat && !ctx->otf) {
         // matrix mode: vector row reads, one or two 16-byte vectors per thread where n allows
         const int V = 16 / (int)elem_size(ctx->elem), nvec = ctx->ld / V;
@@ -2926,15 +3095,25 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
             ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn_vec<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
                                                          (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts));
             HIP_TRY(hipGetLastError());
-            return E_OK;
+            launched = true;
         }
     }
-    int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
-    while ((long)BT * 128 < n && BT < 1024) BT *= 2; // register visited mask: n <= 128*BT
-    if ((long)BT * 128 < n) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 131072");
-    ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
-                                                 (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts, ctx->d_pts, ctx->kind));
-    HIP_TRY(hipGetLastError());
+    if (!launched) {
+        int BT = std::min(1024, std::max(64, pow2_ceil(n / 4)));
+        while ((long)BT * 128 < n && BT < 1024) BT *= 2; // register visited mask: n <= 128*BT
+        if ((long)BT * 128 < n) return fail(ctx, E_EXHAUSTED, "nn kernel supports n <= 131072");
+        ELEM_SWITCH(ctx->elem, T, hipLaunchKernelGGL((k_nn<T>), dim3(count), dim3(BT), 0, ctx->stream, ctx->S,
+                                                     (const T *)ctx->d_mat, n, ctx->ld, slot0, ctx->d_starts, ctx->d_pts, ctx->kind));
+        HIP_TRY(hipGetLastError());
+    }
+    // Only a caller matrix can hold NOT_CONNECTED off the diagonal; built matrices never leave a tour open.
+    if (!ctx->built) {
+        HIP_TRY(hipMemcpyAsync(ctx->h_status, ctx->S.status + slot0, (size_t)count * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < count; i++)
+            if (ctx->h_status[i])
+                return fail(ctx, E_INVALID, "nearest-neighbour tour from start %d is incomplete: a node has no admissible edge left (NOT_CONNECTED entries)", h_starts[i]);
+    }
     return E_OK;
 }
 
@@ -3031,6 +3210,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
+    case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
     return E_OK;
@@ -3117,6 +3297,7 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
         ctx->elem = TSPGPU_ELEM_I32;   // integer deltas; no cells are stored
         ctx->symmetric = true;
         ctx->have_costs = true;
+        ctx->built = true;
         ctx->plan_kernel = 0;
         return E_OK;
     }
@@ -3126,6 +3307,7 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
     if (rc) return rc;
     ctx->symmetric = true; // Euclidean
     ctx->have_costs = true;
+    ctx->built = true;
     ctx->plan_kernel = 0;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (host_out) return tspgpu_get_costs(ctx, host_out);
@@ -3143,6 +3325,7 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
         free_matrix(ctx);
     }
     ctx->otf = false;
+    ctx->built = false;
     const int ld = ctx->ld;
     const size_t cells = (size_t)n * ld;
     double *stage = nullptr;
@@ -3217,6 +3400,7 @@ int tspgpu_nn_tour(tspgpu_ctx *ctx, int start, int *path, double *cost)
     double nn_cost = 0;
     HIP_TRY(hipMemcpyAsync(&nn_cost, ctx->S.cost, 8, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = init_slots(ctx, 0, 1, -1))) return rc; // derives succ[]
+    mark_slots(ctx, 0, 1, true);
     if ((rc = store_path(ctx, 0, path, nullptr, nullptr))) return rc;
     *cost = nn_cost; // the running sum of heuristics.c:276,281, not the node-order recompute
     return E_OK;
@@ -3239,32 +3423,39 @@ int tspgpu_tour_nn(tspgpu_ctx *ctx, int slot, int start)
     if (rc) return rc;
     if ((rc = ensure_tours(ctx, slot + 1))) return rc;
     if ((rc = launch_nn(ctx, slot, &start, 1))) return rc;
-    return init_slots(ctx, slot, 1, -1);
+    if ((rc = init_slots(ctx, slot, 1, -1))) return rc;
+    mark_slots(ctx, slot, 1, true);
+    return E_OK;
 }
 
 int tspgpu_tour_copy(tspgpu_ctx *ctx, int dst, int src)
 {
-    if (!ctx || dst < 0 || src < 0 || src >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    if (!ctx || dst < 0) return fail(ctx, E_INVALID, "bad slot");
     hipSetDevice(ctx->device);
-    if (dst >= ctx->tcap) return fail(ctx, E_INVALID, "destination slot %d not allocated (capacity %d)", dst, ctx->tcap);
+    int rc = need_slot(ctx, src);
+    if (rc) return rc;
+    if ((rc = ensure_tours(ctx, dst + 1))) return rc;
     hipLaunchKernelGGL(k_copy_tour, dim3(std::max(1, ctx->n / 256)), dim3(256), 0, ctx->stream, ctx->S, ctx->n, dst, src);
     HIP_TRY(hipGetLastError());
+    mark_slots(ctx, dst, 1, true);
     return E_OK;
 }
 
 int tspgpu_tour_two_opt(tspgpu_ctx *ctx, int slot, long max_sweeps, double time_left_s, long *sweeps)
 {
-    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    if (!ctx) return E_INVALID;
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
+    if ((rc = need_slot(ctx, slot))) return rc;
     hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, ctx->stream, ctx->S, slot, 1, (int)std::min<long>(max_sweeps, INT_MAX));
     HIP_TRY(hipGetLastError());
     bool late = false;
     if ((rc = run_sweeps(ctx, slot, 1, false, -1, time_left_s, &late))) return rc;
     if (sweeps) {
-        int ns = 0;
-        HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps + slot, 4, hipMemcpyDeviceToHost));
+        int ns = 0;   // on the engine's stream: it is non-blocking, a null-stream copy would not order after it
+        HIP_TRY(hipMemcpyAsync(&ns, ctx->S.nsweeps + slot, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         *sweeps = ns;
     }
     return late ? E_DEADLINE : E_OK;
@@ -3272,8 +3463,10 @@ int tspgpu_tour_two_opt(tspgpu_ctx *ctx, int slot, long max_sweeps, double time_
 
 int tspgpu_tour_store(tspgpu_ctx *ctx, int slot, int *path, double *cost, double *last_delta)
 {
-    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad slot");
+    if (!ctx) return E_INVALID;
     hipSetDevice(ctx->device);
+    int rc = need_slot(ctx, slot);
+    if (rc) return rc;
     return store_path(ctx, slot, path, cost, last_delta);
 }
 
@@ -3308,7 +3501,8 @@ int tspgpu_two_opt(tspgpu_ctx *ctx, int *path, double *cost, double time_left_s,
     if ((rc = run_sweeps(ctx, 0, 1, false, -1, time_left_s, &late))) return rc;
     if (sweeps) {
         int ns = 0;
-        HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         *sweeps = ns;
     }
     if ((rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
@@ -3408,6 +3602,7 @@ int tspgpu_nn_all_timed(tspgpu_ctx *ctx, const int *starts, int nstarts, double 
         if (win >= 0) {
             arg = hs[win];
             if ((rc = init_slots(ctx, win, 1, -1))) return rc;
+            mark_slots(ctx, win, 1, true);
             if ((rc = store_path(ctx, win, best_path, nullptr, nullptr))) return rc;
         }
         base += m;
@@ -3445,7 +3640,8 @@ int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, d
         const int m = std::min(chunk, nstarts - base);
         for (int i = 0; i < m; i++) hs[i] = starts ? starts[base + i] : base + i;
         if ((rc = launch_nn(ctx, 0, hs.data(), m))) return rc;
-        if ((rc = init_slots(ctx, 0, m, -1))) return rc;
+        if ((rc = init_slots(ctx, 0, m, ctx->opt_sweep_cap))) return rc;
+        mark_slots(ctx, 0, m, true);
         const double left = t_end >= 0 ? std::max(0.0, t_end - now_s()) : -1;
         if ((rc = run_sweeps(ctx, 0, m, false, -1, left, &late))) return rc;
         HIP_TRY(hipMemcpyAsync(ctx->h_costs, ctx->S.cost, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -3460,7 +3656,9 @@ int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, d
             arg = hs[win];
             if ((rc = store_path(ctx, win, best_path, nullptr, nullptr))) return rc;
         }
-        if (base + m >= nstarts && last_path) {
+        // what h_Greedy_2opt_mod_costs leaves in *solution: the tour of the last start it processed -- the last
+        // one of the list, or of the chunk in which the deadline struck (always a valid tour, heuristics.c:118-149)
+        if ((late || base + m >= nstarts) && last_path) {
             if ((rc = store_path(ctx, m - 1, last_path, last_cost, nullptr))) return rc;
         }
     }
@@ -3471,11 +3669,12 @@ int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts, d
 
 int tspgpu_tour_sweep_part(tspgpu_ctx *ctx, int slot, int part, int nparts, double *delta, int *a, int *b)
 {
-    if (!ctx || !delta || !a || !b || slot < 0 || slot >= ctx->tcap || nparts <= 0 || part < 0 || part >= nparts)
+    if (!ctx || !delta || !a || !b || nparts <= 0 || part < 0 || part >= nparts)
         return fail(ctx, E_INVALID, "bad argument");
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
+    if ((rc = need_slot(ctx, slot))) return rc;
     if (!ctx->symmetric) return fail(ctx, E_PRECOND, "a sharded sweep needs a symmetric matrix (both orientations of a pair live in different parts otherwise)");
     if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
     const int G = ctx->plan_G;
@@ -3497,12 +3696,13 @@ int tspgpu_tour_sweep_part(tspgpu_ctx *ctx, int slot, int part, int nparts, doub
 
 int tspgpu_tour_apply_move(tspgpu_ctx *ctx, int slot, int a, int b, double delta)
 {
-    if (!ctx || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad argument");
+    if (!ctx) return E_INVALID;
     const int n = ctx->n;
     if (a < 0 || b < 0 || a >= n || b >= n) return fail(ctx, E_INVALID, "move (%d,%d) outside [0,%d)", a, b, n);
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
+    if ((rc = need_slot(ctx, slot))) return rc;
     if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
     const int G = ctx->plan_G;
     const u64 key = delta < TWO_OPT_EPS ? (a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a) : 0;
@@ -3515,10 +3715,11 @@ int tspgpu_tour_apply_move(tspgpu_ctx *ctx, int slot, int a, int b, double delta
 
 int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean)
 {
-    if (!ctx || !ms_mean || reps <= 0 || slot < 0 || slot >= ctx->tcap) return fail(ctx, E_INVALID, "bad argument");
+    if (!ctx || !ms_mean || reps <= 0) return fail(ctx, E_INVALID, "bad argument");
     hipSetDevice(ctx->device);
     int rc = need_costs(ctx);
     if (rc) return rc;
+    if ((rc = need_slot(ctx, slot))) return rc;
     if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
     hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, ctx->stream, ctx->S, slot, 1, -1);
     hipEvent_t e0, e1;
@@ -3581,12 +3782,16 @@ int tspgpu_history(tspgpu_ctx *ctx, int *a, int *b, double *delta, int capacity,
     if (!ctx || !count) return fail(ctx, E_INVALID, "null argument");
     hipSetDevice(ctx->device);
     int ns = 0;
-    if (ctx->tcap > 0) HIP_TRY(hipMemcpy(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost));
+    if (ctx->tcap > 0) {
+        HIP_TRY(hipMemcpyAsync(&ns, ctx->S.nsweeps, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     int m = std::min(std::min(ns, ctx->hist.cap), capacity);
     if (m > 0) {
-        if (a) HIP_TRY(hipMemcpy(a, ctx->hist.a, (size_t)m * 4, hipMemcpyDeviceToHost));
-        if (b) HIP_TRY(hipMemcpy(b, ctx->hist.b, (size_t)m * 4, hipMemcpyDeviceToHost));
-        if (delta) HIP_TRY(hipMemcpy(delta, ctx->hist.d, (size_t)m * 8, hipMemcpyDeviceToHost));
+        if (a) HIP_TRY(hipMemcpyAsync(a, ctx->hist.a, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (b) HIP_TRY(hipMemcpyAsync(b, ctx->hist.b, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (delta) HIP_TRY(hipMemcpyAsync(delta, ctx->hist.d, (size_t)m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     *count = m;
     return E_OK;

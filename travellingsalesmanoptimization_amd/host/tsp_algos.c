@@ -17,8 +17,78 @@
 
 #include "tspgpu.h"
 
-static __thread tspgpu_ctx *tl_ctx = NULL;      /* per-thread context for caller-supplied matrices */
-static __thread const double *tl_costs = NULL;
+/* Per-thread contexts for caller-supplied matrices.  A context holds a stream, an n x n matrix and tour slots
+ * on the device, so its lifetime is managed: a pthread key destructor destroys it when its thread exits (CPLEX
+ * tears its worker threads down after the solve), and whatever is still alive when the instance is freed goes in
+ * tsp_gpu_release_threads().  The registry (mutex-protected list) is what makes the second path possible. */
+#include <pthread.h>
+
+typedef struct thread_ctx {
+    tspgpu_ctx *gpu;
+    struct thread_ctx *next;
+} thread_ctx;
+
+static pthread_mutex_t reg_lock = PTHREAD_MUTEX_INITIALIZER;
+static thread_ctx *reg_head = NULL;
+static int reg_live = 0;
+static pthread_key_t reg_key;
+static pthread_once_t reg_once = PTHREAD_ONCE_INIT;
+
+static void reg_unlink(thread_ctx *t)
+{
+    for (thread_ctx **pp = &reg_head; *pp; pp = &(*pp)->next)
+        if (*pp == t) { *pp = t->next; reg_live--; break; }
+}
+
+static void thread_ctx_exit(void *arg)          /* runs in the exiting thread */
+{
+    thread_ctx *t = (thread_ctx *)arg;
+    pthread_mutex_lock(&reg_lock);
+    reg_unlink(t);
+    pthread_mutex_unlock(&reg_lock);
+    tspgpu_destroy(t->gpu);
+    free(t);
+}
+
+static void reg_make_key(void) { pthread_key_create(&reg_key, thread_ctx_exit); }
+
+int tsp_gpu_thread_contexts(void)
+{
+    pthread_mutex_lock(&reg_lock);
+    const int live = reg_live;
+    pthread_mutex_unlock(&reg_lock);
+    return live;
+}
+
+/* destroys the contexts of threads that are still alive; they re-create theirs on the next call */
+void tsp_gpu_release_threads(void)
+{
+    pthread_mutex_lock(&reg_lock);
+    for (thread_ctx *t = reg_head; t; t = t->next) {
+        if (t->gpu) tspgpu_destroy(t->gpu);
+        t->gpu = NULL;
+    }
+    pthread_mutex_unlock(&reg_lock);
+}
+
+static tspgpu_ctx *thread_gpu(void)
+{
+    pthread_once(&reg_once, reg_make_key);
+    thread_ctx *t = (thread_ctx *)pthread_getspecific(reg_key);
+    if (!t) {
+        t = (thread_ctx *)calloc(1, sizeof *t);
+        if (!t) return NULL;
+        pthread_setspecific(reg_key, t);
+        pthread_mutex_lock(&reg_lock);
+        t->next = reg_head; reg_head = t; reg_live++;
+        pthread_mutex_unlock(&reg_lock);
+    }
+    if (!t->gpu) {
+        const char *dev = getenv("TSP_GPU_DEVICE");
+        if (tspgpu_create(dev ? atoi(dev) : 0, &t->gpu) != 0) { t->gpu = NULL; return NULL; }
+    }
+    return t->gpu;
+}
 
 static double time_left(void)
 {
@@ -32,23 +102,19 @@ static bool past_deadline(void)
     return tsp_env.timelimit != -1.0 && utils_timeelapsed(&tsp_inst.c) > tsp_env.timelimit;
 }
 
-/* context holding `costs`; force = upload even if the pointer was seen before (the caller
- * may have refilled the same buffer) */
-static tspgpu_ctx *ctx_for(double *costs, bool force)
+/* Context holding `costs`.  The instance's own matrix lives in the process-wide context; any other pointer is a
+ * caller matrix and is uploaded into the calling thread's context on EVERY call: the pointer says nothing about
+ * the contents (cplex_model.c:1176-1258 refills one buffer per callback), so nothing is cached across calls. */
+static tspgpu_ctx *ctx_for(double *costs)
 {
     if (costs == tsp_inst.costs) return tsp_gpu();
-    if (!tl_ctx) {
-        const char *dev = getenv("TSP_GPU_DEVICE");
-        if (tspgpu_create(dev ? atoi(dev) : 0, &tl_ctx) != 0) return NULL;
+    tspgpu_ctx *g = thread_gpu();
+    if (!g) return NULL;
+    if (tspgpu_set_costs(g, costs, tsp_inst.nnodes) != 0) {
+        log_error("tspgpu_set_costs: %s", tspgpu_last_error(g));
+        return NULL;
     }
-    if (force || tl_costs != costs) {
-        if (tspgpu_set_costs(tl_ctx, costs, tsp_inst.nnodes) != 0) {
-            log_error("tspgpu_set_costs: %s", tspgpu_last_error(tl_ctx));
-            return NULL;
-        }
-        tl_costs = costs;
-    }
-    return tl_ctx;
+    return g;
 }
 
 static ERROR_CODE from_rc(int rc) { return (ERROR_CODE)rc; }
@@ -59,7 +125,7 @@ static ERROR_CODE from_rc(int rc) { return (ERROR_CODE)rc; }
  * (tspgpu_two_opt); the deadline is polled once per batch of sweeps instead of per sweep. */
 ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent)
 {
-    tspgpu_ctx *g = ctx_for(costs, false);
+    tspgpu_ctx *g = ctx_for(costs);
     if (!g) return UNAVAILABLE;
     ERROR_CODE e = T_OK;
     if (past_deadline()) {
@@ -88,7 +154,7 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
 /* refinment.c:39-93 */
 double ref_2opt_once(tsp_solution *solution, double *costs)
 {
-    tspgpu_ctx *g = ctx_for(costs, false);
+    tspgpu_ctx *g = ctx_for(costs);
     double delta = 0;
     if (!g || tspgpu_two_opt_once(g, solution->path, &solution->cost, &delta) != 0) {
         log_error("tspgpu_two_opt_once failed: %s", g ? tspgpu_last_error(g) : "no device");
@@ -119,7 +185,7 @@ ERROR_CODE h_greedyutil(int starting_node, tsp_solution *solution, double *costs
     if (!costs && !tsp_matrix_free) { log_error("matrix of costs not found"); return INTERNAL; }
     if (starting_node >= tsp_inst.nnodes || starting_node < 0) { log_error("starting node not correct"); return UNAVAILABLE; }
     if (past_deadline()) { log_warn("time limit exceeded in greedy util"); return DEADLINE_EXCEEDED; }
-    tspgpu_ctx *g = ctx_for(costs, false);
+    tspgpu_ctx *g = ctx_for(costs);
     if (!g) return UNAVAILABLE;
     int rc = tspgpu_nn_tour(g, starting_node, solution->path, &solution->cost);
     if (rc) log_error("tspgpu_nn_tour: %s", tspgpu_last_error(g));
@@ -198,7 +264,7 @@ ERROR_CODE h_greedy_2opt(void)
 ERROR_CODE h_Greedy_2opt_mod_costs(tsp_solution *solution, double *costs)
 {
     if (past_deadline()) return DEADLINE_EXCEEDED;
-    tspgpu_ctx *g = ctx_for(costs, true);
+    tspgpu_ctx *g = ctx_for(costs);
     if (!g) return UNAVAILABLE;
     const int n = tsp_inst.nnodes;
     int *best = (int *)malloc((size_t)n * sizeof(int));

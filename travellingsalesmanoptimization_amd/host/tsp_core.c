@@ -36,6 +36,7 @@ struct tspgpu_ctx *tsp_gpu(void)
 
 void tsp_gpu_release(void)
 {
+    tsp_gpu_release_threads();          /* contexts of caller-matrix threads that are still alive (tsp_algos.c) */
     if (g_ctx) tspgpu_destroy(g_ctx);
     g_ctx = NULL;
 }

@@ -169,6 +169,10 @@ extern bool tsp_matrix_free;
 struct tspgpu_ctx;
 struct tspgpu_ctx *tsp_gpu(void);
 void tsp_gpu_release(void);
+/* caller-matrix calls (h_Greedy_2opt_mod_costs from CPLEX callback threads, cplex_model.c:1176-1258) run in a
+ * device context private to the calling thread; it is destroyed when the thread exits.  Live count / early release: */
+int tsp_gpu_thread_contexts(void);
+void tsp_gpu_release_threads(void);
 
 #ifdef __cplusplus
 }

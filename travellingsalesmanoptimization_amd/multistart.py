@@ -39,13 +39,15 @@ def pack_key(cost, start, rank=0):
     return (c << 32) | (int(start) << 8) | int(rank)
 
 
-def select_best(cost, start, path, device="cpu", group=None):
+def select_best(cost, start, path, device="cpu", group=None, force=False):
     """All ranks call this with their local winner; every rank returns the global
     (cost, start, path).  `start` < 0 means "nothing found on this rank".
-    Collectives: ONE all-reduce(MIN) of the packed key + one broadcast of the winner's tour."""
+    Collectives: ONE all-reduce(MIN) of the packed key + one broadcast of the winner's tour.
+    A single rank needs no exchange and issues none, unless `force` asks for the collectives
+    anyway (the 1-rank RCCL smoke test: the exact calls of the N-rank path on one GPU)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     n = len(path)
-    if world == 1:
+    if world == 1 and not (force and dist.is_initialized()):
         return cost, start, path
     rank = dist.get_rank(group)
     none = start < 0
