@@ -145,9 +145,48 @@ int tspgpu_multistart_nn_2opt(tspgpu_ctx *ctx, const int *starts, int nstarts,
                               int *best_start, long *total_sweeps,
                               int *last_path, double *last_cost);
 
+/* ---- multi-device multi-start (csrc/tspgpu_multi.cpp) ------------------------
+ * The reference's multi-start loops (h_greedy_2opt, src/algorithms/heuristics.c:82-111; h_Greedy_iterative, :43-66)
+ * are sequential C; their iterations are independent except for the incumbent minimum (src/tsp.c:669-676, strict <).
+ * Here one process drives several MI355X: one engine context and one host thread per device, entry p of the start
+ * list on device p mod G, every device building its own matrix from the coordinates, and ONE exchange per call:
+ * ncclAllReduce(ncclMin) over xGMI of one packed int64 per device (cost:31 | list position:24 | device rank:8: lowest
+ * cost, ties to the earliest start -- the sequential strict-< result -- and the low byte names the owner), then
+ * ncclBroadcast of the owner's successor array (4n bytes).  RCCL is dlopen'ed at the first exchange that needs it.
+ * A device id may be listed more than once (several contexts on one GPU, how the sharding is exercised on a
+ * one-GPU box); an RCCL communicator needs distinct devices, so that list exchanges on the host. */
+typedef struct tspgpu_multi tspgpu_multi;
+enum { TSPGPU_MOPT_EXCHANGE = 1000 };   /* tspgpu_multi_set_option: 0 auto (RCCL when G > 1 distinct devices, none for
+                                           G = 1, host for a repeated device), 1 host, 2 RCCL (also with G = 1: a
+                                           one-rank communicator; refused for a repeated device).  Every other option
+                                           is a TSPGPU_OPT_* applied to each device's context. */
+int  tspgpu_multi_create(const int *device_ids, int ndev, tspgpu_multi **out);
+void tspgpu_multi_destroy(tspgpu_multi *m);
+const char *tspgpu_multi_last_error(const tspgpu_multi *m);
+int  tspgpu_multi_devices(const tspgpu_multi *m);
+tspgpu_ctx *tspgpu_multi_ctx(tspgpu_multi *m, int i);          /* the i-th device's context (owned by m) */
+/* info: 0 devices, 1 exchange the next call will use (0 none, 1 host, 2 RCCL), 2 exchange used by the last call,
+ * 3 seconds spent in ncclCommInitAll, 4 seconds of the last exchange, 5 seconds of the last per-device solve,
+ * 6 exchanges so far, 7 the device ids are distinct */
+double tspgpu_multi_info(const tspgpu_multi *m, int what);
+int  tspgpu_multi_set_option(tspgpu_multi *m, int option, long value);
+int  tspgpu_multi_set_points(tspgpu_multi *m, const double *xy, int n, int edge_weight_type);
+int  tspgpu_multi_build_costs(tspgpu_multi *m);                 /* tsp_compute_costs on every device */
+/* h_greedy_2opt (src/algorithms/heuristics.c:74-116) sharded over the devices; same results as
+ * tspgpu_multistart_nn_2opt over the whole list when no deadline is set */
+int  tspgpu_multi_multistart_nn_2opt(tspgpu_multi *m, const int *starts, int nstarts, double time_left_s,
+                                     int *best_path, double *best_cost, int *best_start, long *total_sweeps);
+/* h_Greedy_iterative (src/algorithms/heuristics.c:34-72) sharded the same way */
+int  tspgpu_multi_nn_all(tspgpu_multi *m, const int *starts, int nstarts, double time_left_s,
+                         int *best_path, double *best_cost, int *best_start, int *done_starts);
+
 /* ---- device-resident variants (inputs already in HBM; used by bench.py) --- */
 
-/* upload a successor array into tour slot `slot` (0 <= slot < max tours) */
+/* Tour slots: the slot array grows on demand and keeps what the existing slots hold; a slot holds a tour once
+ * something was loaded / built / copied into it, and until the next tspgpu_build_costs / tspgpu_set_costs (its edge
+ * costs belong to the matrix).  Slot entry points answer FAILED_PRECONDITION (9) for a slot that holds none.
+ * The host-array entry points above and the multi-start entry points use slots from 0 upwards as scratch. */
+/* upload a successor array into tour slot `slot` */
 int tspgpu_tour_load(tspgpu_ctx *ctx, int slot, const int *path);
 /* NN tour built on the device straight into a slot */
 int tspgpu_tour_nn(tspgpu_ctx *ctx, int slot, int start);

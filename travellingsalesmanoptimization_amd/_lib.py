@@ -20,6 +20,8 @@ EUC_2D, ATT, CEIL_2D = 0, 1, 2
 ELEM_AUTO, ELEM_F64, ELEM_I32, ELEM_U16 = 0, 1, 2, 3
 OPT_ELEM, OPT_KERNEL, OPT_BATCH, OPT_WGS_PER_TOUR, OPT_HISTORY = 1, 2, 3, 4, 5
 OPT_GRAPH, OPT_TIMING, OPT_BLOCK, OPT_MAX_TOURS, OPT_DEPTH, OPT_MATRIX_FREE, OPT_FUSED, OPT_SWEEP_CAP = 6, 7, 8, 9, 10, 11, 12, 13
+MOPT_EXCHANGE = 1000
+EXCHANGE_AUTO, EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1, 2
 
 _dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
 _ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
@@ -51,6 +53,17 @@ SIGNATURES = {
     "tspgpu_nn_all_timed": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pi]),
     "tspgpu_multistart_nn_2opt": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pl,
                                             C.c_void_p, C.c_void_p]),
+    "tspgpu_multi_create": (C.c_int, [_ip, C.c_int, C.POINTER(_ctx)]),
+    "tspgpu_multi_destroy": (None, [_ctx]),
+    "tspgpu_multi_last_error": (C.c_char_p, [_ctx]),
+    "tspgpu_multi_devices": (C.c_int, [_ctx]),
+    "tspgpu_multi_ctx": (_ctx, [_ctx, C.c_int]),
+    "tspgpu_multi_info": (C.c_double, [_ctx, C.c_int]),
+    "tspgpu_multi_set_option": (C.c_int, [_ctx, C.c_int, C.c_long]),
+    "tspgpu_multi_set_points": (C.c_int, [_ctx, _dp, C.c_int, C.c_int]),
+    "tspgpu_multi_build_costs": (C.c_int, [_ctx]),
+    "tspgpu_multi_multistart_nn_2opt": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pl]),
+    "tspgpu_multi_nn_all": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pi]),
     "tspgpu_tour_load": (C.c_int, [_ctx, C.c_int, _ip]),
     "tspgpu_tour_nn": (C.c_int, [_ctx, C.c_int, C.c_int]),
     "tspgpu_tour_copy": (C.c_int, [_ctx, C.c_int, C.c_int]),

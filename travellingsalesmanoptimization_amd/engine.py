@@ -208,6 +208,74 @@ class Engine:
         return a[:m.value], b[:m.value], d[:m.value]
 
 
+class MultiEngine:
+    """Python handle on one tspgpu_multi (several MI355X driven by one process, include/tspgpu.h
+    "multi-device"): start list sharded over the devices, ONE RCCL MIN all-reduce + ONE broadcast per call."""
+
+    def __init__(self, devices):
+        self.L = _lib.load()
+        self.m = C.c_void_p()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        rc = self.L.tspgpu_multi_create(dev, len(dev), C.byref(self.m))
+        if rc != T_OK:
+            raise TspGpuError(rc, f"tspgpu_multi_create{tuple(int(d) for d in dev)} failed")
+        self.n = 0
+
+    def close(self):
+        if self.m:
+            self.L.tspgpu_multi_destroy(self.m)
+            self.m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, ok=(T_OK,)):
+        if rc not in ok:
+            raise TspGpuError(rc, self.L.tspgpu_multi_last_error(self.m).decode())
+        return rc
+
+    def set_option(self, opt, value):
+        self._ck(self.L.tspgpu_multi_set_option(self.m, opt, int(value)))
+
+    def info(self):
+        names = ["devices", "exchange_next", "exchange_last", "rccl_init_s", "exchange_s", "solve_s", "exchanges", "distinct"]
+        return {k: self.L.tspgpu_multi_info(self.m, i) for i, k in enumerate(names)}
+
+    def device_info(self, i):
+        ctx = self.L.tspgpu_multi_ctx(self.m, i)
+        names = ["n", "ld", "elem", "kernel", "wgs_per_tour", "lds_bytes", "block", "symmetric", "cus", "depth", "matrix_free", "fused"]
+        return {k: int(self.L.tspgpu_info(ctx, j)) for j, k in enumerate(names)}
+
+    def set_points(self, xy, kind=EUC_2D):
+        xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+        self.n = len(xy) // 2
+        self._ck(self.L.tspgpu_multi_set_points(self.m, xy, self.n, kind))
+
+    def build_costs(self):
+        self._ck(self.L.tspgpu_multi_build_costs(self.m))
+
+    def multistart_nn_2opt(self, starts=None, time_left_s=-1.0):
+        """h_greedy_2opt (heuristics.c:74-116) over every device -> dict."""
+        p, m, keep = Engine._starts(starts, self.n)
+        best = np.empty(self.n, dtype=np.int32)
+        c, s, sw = C.c_double(), C.c_int(), C.c_long()
+        rc = self._ck(self.L.tspgpu_multi_multistart_nn_2opt(self.m, p, m, float(time_left_s), best, C.byref(c), C.byref(s), C.byref(sw)),
+                      ok=(T_OK, DEADLINE_EXCEEDED))
+        return {"path": best, "cost": c.value, "start": s.value, "sweeps": sw.value, "rc": rc}
+
+    def nn_all(self, starts=None, time_left_s=-1.0):
+        """h_Greedy_iterative (heuristics.c:34-72) over every device -> (best_path, best_cost, best_start, done, rc)."""
+        p, m, keep = Engine._starts(starts, self.n)
+        best = np.empty(self.n, dtype=np.int32)
+        c, s, d = C.c_double(), C.c_int(), C.c_int()
+        rc = self._ck(self.L.tspgpu_multi_nn_all(self.m, p, m, float(time_left_s), best, C.byref(c), C.byref(s), C.byref(d)),
+                      ok=(T_OK, DEADLINE_EXCEEDED))
+        return best, c.value, s.value, d.value, rc
+
+
 def evals_per_sweep(n):
     """valid pairs per sweep = n(n-3)/2 (adjacent pairs are skipped, refinment.c:55)."""
     return n * (n - 3) // 2
