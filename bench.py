@@ -7,10 +7,10 @@
 
 One STEP = one full best-improvement 2-opt local search on the device: the nearest-
 neighbour tour (already resident in HBM, next to the cost matrix) is copied into a work
-slot and swept to its local optimum -- hundreds of (sweep, apply-move) launch pairs,
-exactly the trajectory of the reference's ref_2opt (src/algorithms/refinment.c:3-37).
-Matrix build and NN construction are outside the timed region, as in the reference
-(src/main.c:177 starts the clock after tsp_compute_costs) and SURVEY 8(d).
+slot and swept to its local optimum -- hundreds of one-launch-per-sweep kernels, exactly the
+trajectory of the reference's ref_2opt (src/algorithms/refinment.c:3-37).  Matrix build and NN
+construction are outside the timed region, as in the reference (src/main.c:177 starts the
+clock after tsp_compute_costs) and SURVEY 8(d).
 
   value        = valid pair evaluations per second, whole job: sum over ranks of
                  sweeps * n(n-3)/2, divided by the max-over-ranks wall time
@@ -19,14 +19,27 @@ Matrix build and NN construction are outside the timed region, as in the referen
                  h_greedy_2opt, heuristics.c:82-111, sharded), then ONE RCCL MIN
                  all-reduce picks the best tour and its owner broadcasts it (4n bytes).
 
-Extra objects on the JSON line: "roofline" (dominant kernel = the sweep kernel; achieved =
-algorithmic bytes per launch / mean kernel duration from HIP events on the engine's
-stream) and "cpu_baseline" (the reference's own CPU 2-opt on this box's host, 1 core,
-bounded sample).  Nothing here reads /root/reference.
+Objects on the same JSON line (rank 0; the auxiliary legs run after the timed region):
+  roofline               dominant kernel (the sweep): algorithmic bytes per launch / mean launch duration from HIP events
+                         on the engine's stream, against the 8 TB/s HBM peak
+  roofline_build         K1 (k_build_costs): bytes stored / launch duration against the same peak
+  cpu_baseline           the reference's own CPU 2-opt on this box's host, 1 core, bounded sample
+  other_matrix_storage   the same workload with the reference's own f64 cells (16 B / evaluation)
+  sizes                  the n = 1024 and n = 16384 rows of north_star's throughput table (each with its own parity gate
+                         against a committed golden, its roofline and a bounded CPU sample)
+  multistart_batch       64 starts in flight (NN + 2-opt, the throughput-bound regime)
+  otf                    matrix-free sweep on pla85900 (config 5): bound "valu", ceiling from the kernel's ISA
+                         (tools/otf_isa_count.py -> profiles/r02_otf_isa_ceiling.json)
+  cpu_multistart_baseline  All-NN+2OPT on pr1002, all 1002 starts: the reference on ALL host cores of this box's share
+                         (one process per core over disjoint start ranges) next to the engine's time
+  host_c_path            the drop-in `tsp` binary (C host layer, TSP_GPU_DEVICES = the N devices of this run): the
+                         multi-start sharded in C, exchange by RCCL (csrc/tspgpu_multi.cpp)
+Nothing here reads /root/reference; goldens and instances come from tests/golden/.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,6 +47,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+DATA = os.path.join(GOLDEN, "data")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 
@@ -52,7 +67,46 @@ def reference_points(n, seed):
     return xy
 
 
-def cpu_baseline(n, seed, sample_sweeps):
+def read_tsplib(path):
+    """NODE_COORD_SECTION reader (instances under tests/golden/data)"""
+    n, xy, on, ewt = None, None, False, "EUC_2D"
+    with open(path) as f:
+        for line in f:
+            t = line.replace(":", " ").split()
+            if not t:
+                continue
+            if on:
+                if t[0] == "EOF":
+                    break
+                xy[int(t[0]) - 1] = (float(t[1]), float(t[2]))
+            elif t[0] == "DIMENSION":
+                n = int(t[1]); xy = np.zeros((n, 2), dtype=np.float64)
+            elif t[0] == "EDGE_WEIGHT_TYPE":
+                ewt = t[1]
+            elif t[0] == "NODE_COORD_SECTION":
+                on = True
+    return xy, ewt
+
+
+def fnv1a(succ):
+    """64-bit FNV-1a over the successor array, one step per node (the hash of the golden fixtures)"""
+    h = 0xcbf29ce484222325
+    for v in np.asarray(succ, dtype=np.int64).tolist():
+        h = ((h ^ (v & 0xFFFFFFFF)) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return f"{h:016x}"
+
+
+def golden_two_opt(n, seed):
+    """committed golden of the NN(0) -> local optimum search on `-n n -seed seed` (from the compiled reference)"""
+    try:
+        if n == 16384 and seed == 123:
+            return json.load(open(os.path.join(GOLDEN, "golden_n16384_s123.json")))["two_opt"]
+        return json.load(open(os.path.join(GOLDEN, "golden.json")))["random"][f"n{n}_s{seed}"]["two_opt"]
+    except (OSError, KeyError):
+        return None
+
+
+def cpu_baseline(n, seed, sample_sweeps, prefer_port=False):
     """The reference's CPU 2-opt on this host, one core (the reference is single-threaded).
     kind "reference": oracle/_ref/libtspref.so = the reference's own sources compiled in the
     authoring container; kind "port": oracle/cpu_ref.c (bit-identical restatement)."""
@@ -60,6 +114,8 @@ def cpu_baseline(n, seed, sample_sweeps):
     import oracle as O
     evals = n * (n - 3) // 2
     try:
+        if prefer_port:
+            raise FileNotFoundError
         ref = O.Reference()
         ref.random(n, seed)
         succ, _, _ = ref.nn(0)
@@ -81,6 +137,49 @@ def cpu_baseline(n, seed, sample_sweeps):
             "ms_per_sweep": 1e3 * dt / sweeps, "host_cores_available": os.cpu_count()}
 
 
+def _cpu_multistart_worker(args):
+    """one process of the all-cores CPU baseline: NN + ref_2opt from starts [lo, hi) with the reference's own code"""
+    path, lo, hi = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    try:
+        ref = O.Reference(scratch=os.path.join("/tmp", f"tspref_scratch_{os.getpid()}"))
+        ref.read_file(path)
+        kind = "reference"
+        best = (float("inf"), -1)
+        t0 = time.perf_counter()
+        for s in range(lo, hi):
+            succ, _, _ = ref.nn(s)
+            c = ref.ref_2opt(succ)
+            if c < best[0]:
+                best = (c, s)
+        return best, time.perf_counter() - t0, kind
+    except (FileNotFoundError, OSError):
+        xy, _ = O.read_tsplib(path)
+        c = O.cost_matrix(xy)
+        t0 = time.perf_counter()
+        p, cost, start, _ = O.multistart_nn_2opt(c, np.arange(lo, hi, dtype=np.int32))
+        return (cost, start), time.perf_counter() - t0, "port"
+
+
+def cpu_multistart_baseline(name, procs):
+    """"for the multi-start comparison only, one process per core over disjoint start-node ranges with
+    nproc stated" -- the whole All-NN+2OPT job of `name` on `procs` host cores."""
+    import multiprocessing as mp
+    path = os.path.join(DATA, name + ".tsp")
+    n = read_tsplib(path)[0].shape[0]
+    cuts = [n * i // procs for i in range(procs + 1)]
+    jobs = [(path, cuts[i], cuts[i + 1]) for i in range(procs) if cuts[i + 1] > cuts[i]]
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(len(jobs)) as pool:
+        res = pool.map(_cpu_multistart_worker, jobs)
+    wall = time.perf_counter() - t0
+    best = min(r[0] for r in res)
+    return {"instance": name, "starts": n, "procs": len(jobs), "host_cores_available": os.cpu_count(),
+            "seconds": wall, "slowest_process_compute_s": max(r[1] for r in res), "best_cost": best[0], "best_start": best[1],
+            "kind": res[0][2], "what": "NN + ref_2opt from every start, reference code, one process per core over disjoint start ranges"}
+
+
 def load_traffic(workload_key):
     """HBM bytes per sweep launch from the committed rocprofv3 PMC passes (profiles/), or None."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
@@ -90,6 +189,14 @@ def load_traffic(workload_key):
         except Exception:
             return None
     return None
+
+
+def guarded(fn, *a, **kw):
+    """an auxiliary leg must not take the bench line down with it"""
+    try:
+        return fn(*a, **kw)
+    except Exception as e:  # noqa: BLE001
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def main():
@@ -109,7 +216,15 @@ def main():
     ap.add_argument("--batch-starts", type=int, default=64, help="starts of the batched multi-start leg (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
     ap.add_argument("--no-sizes", action="store_true", help="skip the n=1024 / n=16384 rows of the throughput table")
+    ap.add_argument("--no-otf", action="store_true", help="skip the matrix-free (pla85900) leg")
+    ap.add_argument("--no-cpu-multistart", action="store_true", help="skip the all-cores CPU multi-start baseline")
+    ap.add_argument("--no-host-c", action="store_true", help="skip the `tsp` binary (C host layer, multi-device) leg")
+    ap.add_argument("--lean", action="store_true", help="headline + roofline only (profiling runs)")
     args = ap.parse_args()
+    if args.lean:
+        args.no_other = args.no_sizes = args.no_otf = args.no_cpu_multistart = args.no_host_c = True
+        args.cpu_sweeps = 0
+        args.batch_starts = 0
 
     import torch
     import torch.distributed as dist
@@ -125,13 +240,98 @@ def main():
         dist.init_process_group("nccl")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     dev = torch.device("cuda", local)
+    aux = rank == 0 and world == 1          # the auxiliary single-GPU legs
+
+    ELEMS = {"auto": T.ELEM_AUTO, "u16": T.ELEM_U16, "i32": T.ELEM_I32, "f64": T.ELEM_F64}
+    NAMES = {T.ELEM_U16: "u16", T.ELEM_I32: "i32", T.ELEM_F64: "f64"}
+    BYTES = {T.ELEM_U16: 2, T.ELEM_I32: 4, T.ELEM_F64: 8}
+    CTYPE = {T.ELEM_U16: "unsigned short", T.ELEM_I32: "int", T.ELEM_F64: "double"}
+
+    def kernel_name(info):
+        if info.get("fused"):
+            return "k_sweep_fused (sweep + apply of the previous move, one launch per sweep)"
+        return {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res", 4: "k_sweep_otf"}[info["kernel"]]
+
+    def timed_search(eng, evals):
+        """the same search once more with HIP events on the engine's stream: around every batch of back-to-back
+        launches on the one-launch-per-sweep path (batch time / launches), around every sweep launch otherwise"""
+        eng.set_option(T.OPT_TIMING, 1)
+        eng.timing_read(reset=True)
+        eng.tour_copy(1, 0)
+        eng.tour_two_opt(1)
+        ms_total, launches = eng.timing_read(reset=True)
+        eng.set_option(T.OPT_TIMING, 0)
+        info = eng.info()
+        bpe = 2 * BYTES[info["elem"]]                     # 2 matrix elements per eval (SURVEY 8d)
+        kernel_ms = ms_total / max(launches, 1)
+        achieved = evals * bpe / (kernel_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,    # PMC counters need their own rocprofv3 pass; the committed pass is quoted beside it
+                "traffic_from_committed_profile": load_traffic(f"n{info['n']}_{NAMES[info['elem']]}" + ("_fused" if info.get("fused") else "")),
+                "kernel": kernel_name(info), "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
+                "algorithmic_bytes_per_launch": evals * bpe, "bytes_per_eval": bpe, "evals_per_launch": evals,
+                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
+
+    def build_roofline(eng):
+        """K1: one launch stores sizeof(cell) * n * ld bytes (write-bound)"""
+        info = eng.info()
+        ms = eng.time_build(5)
+        nbytes = BYTES[info["elem"]] * info["n"] * info["ld"]
+        ach = nbytes / (ms * 1e-3) / 1e9
+        return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": None, "kernel": f"k_build_costs<{CTYPE[info['elem']]}>", "kernel_ms_mean": ms,
+                "algorithmic_bytes_per_launch": nbytes, "bytes_per_cell": BYTES[info["elem"]],
+                "f64_cells_equivalent_GBs": 8 * info["n"] * info["ld"] / (ms * 1e-3) / 1e9}
+
+    def parity(n, seed, sweeps, cost, path):
+        g = golden_two_opt(n, seed)
+        if g is None:
+            return {"golden": None}
+        got = {"sweeps": int(sweeps), "final_cost": float(cost), "final_fnv": fnv1a(path)}
+        ok = all(got[k] == g[k] for k in got)
+        return {"golden": f"tests/golden: n{n}_s{seed} two_opt (compiled reference)", "ok": ok, **got}
+
+    def search_row(n, seed, steps, warmup, elem, cpu_sweeps, port):
+        """one row of the throughput table on its own engine (single GPU)"""
+        evals = T.evals_per_sweep(n)
+        e = T.Engine(local)
+        try:
+            e.set_option(T.OPT_ELEM, ELEMS[elem]); e.set_option(T.OPT_BATCH, args.batch)
+            xy = reference_points(n, seed)
+            e.set_points(xy); e.build_costs()
+            broof = build_roofline(e)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e.tour_nn(0, 0)
+            _, nn_cost, _ = e.tour_store(0, want_path=False)
+            nn_ms = 1e3 * (time.perf_counter() - t0)
+            for _ in range(warmup):
+                e.tour_copy(1, 0); e.tour_two_opt(1)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sw = 0
+            for _ in range(steps):
+                e.tour_copy(1, 0); sw += e.tour_two_opt(1)[0]
+            dt = time.perf_counter() - t0
+            path, cost, _ = e.tour_store(1)
+            info = e.info()
+            row = {"n": n, "seed": seed, "value": sw * evals / dt, "unit": "evals/s", "ms_per_step": 1e3 * dt / steps,
+                   "steps": steps, "sweeps_per_step": sw // steps, "final_cost": cost, "nn_cost": nn_cost, "nn_tour_ms": nn_ms,
+                   "matrix_elem": NAMES[info["elem"]], "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
+                   "block": info["block"], "lds_bytes": info["lds_bytes"],
+                   "parity": parity(n, seed, sw // steps, cost, path),
+                   "roofline": timed_search(e, evals), "roofline_build": broof}
+        finally:
+            e.close()
+        if cpu_sweeps > 0:
+            row["cpu_baseline"] = guarded(cpu_baseline, n, seed, cpu_sweeps, port)
+            if "value" in row["cpu_baseline"]:
+                row["gpu_over_cpu"] = row["value"] / row["cpu_baseline"]["value"]
+        return row
 
     n, seed = args.n, args.seed
     evals = T.evals_per_sweep(n)
     eng = T.Engine(local)
-    ELEMS = {"auto": T.ELEM_AUTO, "u16": T.ELEM_U16, "i32": T.ELEM_I32, "f64": T.ELEM_F64}
-    NAMES = {T.ELEM_U16: "u16", T.ELEM_I32: "i32", T.ELEM_F64: "f64"}
-    BYTES = {T.ELEM_U16: 2, T.ELEM_I32: 4, T.ELEM_F64: 8}
     eng.set_option(T.OPT_ELEM, ELEMS[args.elem])
     eng.set_option(T.OPT_KERNEL, args.kernel)
     eng.set_option(T.OPT_WGS_PER_TOUR, args.wgs)
@@ -142,8 +342,9 @@ def main():
     xy = reference_points(n, seed)
     eng.set_points(xy)
     eng.build_costs()
-    build_ms = eng.time_build(5)
+    broof = build_roofline(eng) if rank == 0 else None
     start = rank % n                       # rank r = the r-th iteration of h_greedy_2opt's loop
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     eng.tour_nn(0, start)
     _, nn_cost, _ = eng.tour_store(0, want_path=False)
@@ -183,111 +384,186 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         tmax, tot_sweeps = float(t.item()), int(s.item())
 
-    # ---- roofline of the dominant kernel: the same search once more with HIP events on the engine's
-    # stream: around every batch of back-to-back launches on the one-launch-per-sweep path (batch
-    # time / launches), around every sweep launch otherwise
+    gate = parity(n, seed, my_sweeps // max(args.steps, 1), final_cost, path) if rank == 0 and start == 0 else None
+    if gate and gate.get("golden") and not gate["ok"]:
+        raise SystemExit(f"parity gate failed: {gate}")        # a fast kernel whose result differs is not a result
+
     roof = None
     if rank == 0:
-        eng.set_option(T.OPT_TIMING, 1)
-        eng.timing_read(reset=True)
-        eng.tour_copy(1, 0)
-        eng.tour_two_opt(1)
-        ms_total, launches = eng.timing_read(reset=True)
-        eng.set_option(T.OPT_TIMING, 0)
-        info = eng.info()
-        bytes_per_eval = 2 * BYTES[info["elem"]]                     # 2 matrix elements per eval
-        kernel_ms = ms_total / max(launches, 1)
-        achieved = evals * bytes_per_eval / (kernel_ms * 1e-3) / 1e9
-        back2back_ms = eng.time_sweep(1, 50)                         # 50 launches, no apply in between
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": load_traffic(f"n{n}_{NAMES[info['elem']]}" + ("_fused" if info.get("fused") else "")),
-                "kernel": "k_sweep_fused (sweep + apply of the previous move, one launch per sweep)" if info.get("fused") else
-                          {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res", 4: "k_sweep_otf"}[info["kernel"]],
-                "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
-                "kernel_ms_back_to_back": back2back_ms,   # the sweep part alone (no move applied between launches)
-                "algorithmic_bytes_per_launch": evals * bytes_per_eval,
-                "bytes_per_eval": bytes_per_eval, "evals_per_launch": evals,
-                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
+        roof = timed_search(eng, evals)
+        roof["kernel_ms_back_to_back"] = eng.time_sweep(1, 50)   # the sweep part alone (no move applied between launches)
 
     base = None
-    if rank == 0 and world == 1 and args.cpu_sweeps > 0:
-        base = cpu_baseline(n, seed, args.cpu_sweeps)
+    if aux and args.cpu_sweeps > 0:
+        base = guarded(cpu_baseline, n, seed, args.cpu_sweeps)
 
-    # ---- the other matrix storage, same workload, for comparison (N = 1 only)
+    # ---- the other matrix storage, same workload: the reference's own f64 cells (N = 1 only)
     other = None
-    if rank == 0 and world == 1 and not args.no_other:
-        oelem = "f64" if eng.info()["elem"] != T.ELEM_F64 else "i32"   # the reference's own format, f64
-        e2 = T.Engine(local)
-        e2.set_option(T.OPT_ELEM, ELEMS[oelem])
-        e2.set_option(T.OPT_BATCH, args.batch)
-        e2.set_points(xy); e2.build_costs(); e2.tour_nn(0, start); e2.tour_copy(1, 0)
-        e2.tour_copy(1, 0); e2.tour_two_opt(1)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        sw2 = 0
-        for _ in range(args.steps):
-            e2.tour_copy(1, 0); sw2 += e2.tour_two_opt(1)[0]
-        dt2 = time.perf_counter() - t1
-        e2.set_option(T.OPT_TIMING, 1); e2.timing_read(reset=True)
-        e2.tour_copy(1, 0); e2.tour_two_opt(1)
-        ms2, l2 = e2.timing_read(reset=True)
-        e2.set_option(T.OPT_TIMING, 0)
-        bpe2 = 16 if oelem == "f64" else 8
-        k2 = ms2 / max(l2, 1)
-        _, c2, _ = e2.tour_store(1, want_path=False)
-        other = {"matrix_elem": oelem, "value": sw2 * evals / dt2, "unit": "evals/s", "ms_per_step": 1e3 * dt2 / args.steps,
-                 "final_cost": c2, "kernel_ms_mean": k2, "bytes_per_eval": bpe2,
-                 "roofline_achieved_GBs": evals * bpe2 / (k2 * 1e-3) / 1e9,
-                 "roofline_frac": evals * bpe2 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                 "traffic": load_traffic(f"n{n}_{oelem}")}
-        e2.close()
+    if aux and not args.no_other:
+        def other_leg():
+            oelem = "f64" if eng.info()["elem"] != T.ELEM_F64 else "i32"
+            e2 = T.Engine(local)
+            try:
+                e2.set_option(T.OPT_ELEM, ELEMS[oelem]); e2.set_option(T.OPT_BATCH, args.batch)
+                e2.set_points(xy); e2.build_costs()
+                b2 = build_roofline(e2)
+                e2.tour_nn(0, start); e2.tour_copy(1, 0); e2.tour_two_opt(1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sw2 = 0
+                for _ in range(args.steps):
+                    e2.tour_copy(1, 0); sw2 += e2.tour_two_opt(1)[0]
+                dt2 = time.perf_counter() - t1
+                p2, c2, _ = e2.tour_store(1)
+                r2 = timed_search(e2, evals)
+                return {"matrix_elem": oelem, "value": sw2 * evals / dt2, "unit": "evals/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                        "final_cost": c2, "parity": parity(n, seed, sw2 // args.steps, c2, p2), "roofline": r2, "roofline_build": b2,
+                        # (flat copies of the two figures round 1 printed)
+                        "kernel_ms_mean": r2["kernel_ms_mean"], "bytes_per_eval": r2["bytes_per_eval"],
+                        "roofline_achieved_GBs": r2["achieved"], "roofline_frac": r2["frac"]}
+            finally:
+                e2.close()
+        other = guarded(other_leg)
 
     # ---- batched multi-start on the same instance (h_greedy_2opt's loop, 64 starts in flight):
     # the throughput-bound regime, next to the latency-bound single search above
     batch = None
-    if rank == 0 and world == 1 and args.batch_starts > 0:
-        starts = np.arange(args.batch_starts, dtype=np.int32)
-        eng.multistart_nn_2opt(starts[:4])
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        res = eng.multistart_nn_2opt(starts)
-        dtb = time.perf_counter() - t1
-        batch = {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
-                 "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"],
-                 "includes": "NN construction + 2-opt of every start, host arrays in/out"}
+    if aux and args.batch_starts > 0:
+        def batch_leg():
+            starts = np.arange(args.batch_starts, dtype=np.int32)
+            eng.multistart_nn_2opt(starts[:4])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = eng.multistart_nn_2opt(starts)
+            dtb = time.perf_counter() - t1
+            return {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
+                    "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"],
+                    "includes": "NN construction + 2-opt of every start, host arrays in/out"}
+        batch = guarded(batch_leg)
 
-    if rank == 0:
-        info = eng.info()
-        out = {
-            "metric": "2-opt delta evals/sec/node (n=4096 EUC_2D, NN(0) tour to 2-opt local optimum)",
-            "value": tot_sweeps * evals / tmax,
-            "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * tmax / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {T.ELEM_U16: "uint16 costs, int32 deltas", T.ELEM_I32: "int32", T.ELEM_F64: "f64"}[info["elem"]],
-            "data": "synthetic",
-            "config": {"workload": f"uniform-random EUC_2D n={n} (reference generator -n {n} -seed {seed}), "
-                                   f"cost matrix resident in HBM, NN(start=rank) tour -> best-improvement 2-opt "
-                                   f"to the local optimum; one step = one full local search",
-                       "n": n, "seed": seed, "evals_per_sweep": evals,
-                       "sweeps_per_step_rank0": my_sweeps // max(args.steps, 1),
-                       "matrix_elem": {T.ELEM_U16: "uint16 exact copy", T.ELEM_I32: "int32 exact copy", T.ELEM_F64: "f64"}[info["elem"]],
-                       "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
-                       "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
-                       "parallelism": f"multistart-shard{world}"},
-            "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
-            "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost,
-            "matrix_build_ms": build_ms, "nn_tour_ms": nn_ms,
-            "roofline": roof, "cpu_baseline": base, "other_matrix_storage": other, "multistart_batch": batch,
-        }
-        if base:
-            out["gpu_over_cpu"] = out["value"] / base["value"]
-        print(json.dumps(out))
+    # ---- the other rows of north_star's throughput table (n = 1k / 16k), each on its own engine
+    sizes = None
+    if aux and not args.no_sizes and n == 4096:
+        sizes = {"1024": guarded(search_row, 1024, 1, max(args.steps, 5), 1, "auto", 174, False),
+                 "16384": guarded(search_row, 16384, 123, 2, 1, "auto", 6, True)}
+
+    # ---- matrix-free sweep (config 5, pla85900): VALU-bound, no HBM roofline
+    otf = None
+    if aux and not args.no_otf:
+        def otf_leg():
+            pts, ewt = read_tsplib(os.path.join(DATA, "pla85900.tsp"))
+            kind = {"EUC_2D": T.EUC_2D, "ATT": T.ATT, "CEIL_2D": T.CEIL_2D}[ewt]
+            e3 = T.Engine(local)
+            try:
+                e3.set_points(pts, kind); e3.build_costs()
+                info = e3.info()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                e3.tour_nn(0, 0)
+                _, c_nn, _ = e3.tour_store(0, want_path=False)
+                nn_s = time.perf_counter() - t1
+                ms = e3.time_sweep(0, 5)
+            finally:
+                e3.close()
+            m = len(pts)
+            ev = T.evals_per_sweep(m)
+            ceil = json.load(open(os.path.join(ROOT, "profiles", "r02_otf_isa_ceiling.json")))["3"]   # CEIL_2D, integer coordinates
+            return {"workload": f"pla85900 ({ewt}, n={m}), matrix-free: no n x n array (59 GB of doubles in the reference's format)",
+                    "matrix_free": info["matrix_free"], "ms_per_sweep": ms, "evals_per_sweep": ev, "value": ev / (ms * 1e-3),
+                    "unit": "evals/s", "nn_tour_s": nn_s, "nn_cost": c_nn,
+                    "roofline": {"bound": "valu", "achieved": ev / (ms * 1e-3), "peak": ceil["ceiling_evals_per_s"], "unit": "evals/s",
+                                 "frac": ev / (ms * 1e-3) / ceil["ceiling_evals_per_s"], "traffic": None,
+                                 "kernel": ceil["kernel"], "issue_cycles_per_pair": ceil["issue_cycles_per_pair"],
+                                 "valu_per_pair": ceil["valu_per_pair"], "clock_hz": ceil["clock_hz"],
+                                 "derivation": "static VALU count of the kernel's ISA priced per instruction class: "
+                                               "tools/otf_isa_count.py -> profiles/r02_otf_isa_ceiling.json (lower bound of the ceiling)"}}
+        otf = guarded(otf_leg)
+
+    # ---- All-NN+2OPT over all 1002 starts of pr1002: the engine vs the reference on every host core of this box's share
+    cpu_ms = None
+    if aux and not args.no_cpu_multistart:
+        def cpu_ms_leg():
+            pts, _ = read_tsplib(os.path.join(DATA, "pr1002.tsp"))
+            e4 = T.Engine(local)
+            try:
+                e4.set_points(pts); e4.build_costs()
+                e4.multistart_nn_2opt(np.arange(8, dtype=np.int32))
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                res = e4.multistart_nn_2opt()
+                gsec = time.perf_counter() - t1
+            finally:
+                e4.close()
+            procs = min(16, len(os.sched_getaffinity(0)))      # the box's CPU share for one GPU
+            out = cpu_multistart_baseline("pr1002", procs)
+            out.update({"gpu_seconds": gsec, "gpu_best_cost": res["cost"], "gpu_sweeps": int(res["sweeps"]),
+                        "gpu_evals_per_s": res["sweeps"] * T.evals_per_sweep(len(pts)) / gsec,
+                        "same_result": res["cost"] == out["best_cost"], "gpu_over_all_cores": out["seconds"] / gsec})
+            return out
+        cpu_ms = guarded(cpu_ms_leg)
+
+    info = eng.info() if rank == 0 else None
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        return
+
+    # ---- the drop-in binary: C host layer, multi-start sharded in C over the N devices of this run, RCCL exchange.
+    # A child process (its own HIP context); at N > 1 the other ranks have left and released their devices.
+    host_c = None
+    if not args.no_host_c:
+        def host_c_leg():
+            tsp = os.path.join(ROOT, "travellingsalesmanoptimization_amd", "host", "tsp")
+            ndev = min(world, int(T._lib.load().tspgpu_device_count()))
+            env = dict(os.environ, TSP_GPU_DEVICES=",".join(str(i) for i in range(ndev)), TSP_GPU_EXCHANGE="rccl", TSP_GPU_STATS="1")
+            out = {"devices": ndev, "exchange": "rccl (ncclAllReduce(ncclMin, int64) + ncclBroadcast, one process, one thread per device)"}
+            for key, argv, tmo in [("pr1002_all_starts", ["-f", os.path.join(DATA, "pr1002.tsp"), "-alg", "2OPT_GREEDY", "-q"], 180),
+                                   ("d18512_t10", ["-f", os.path.join(DATA, "d18512.tsp"), "-alg", "2OPT_GREEDY", "-t", "10", "-q"], 240)]:
+                t1 = time.perf_counter()
+                r = subprocess.run([tsp, *argv], capture_output=True, text=True, timeout=tmo, env=env, cwd=ROOT)
+                wall = time.perf_counter() - t1
+                st = [json.loads(l.split("tspgpu-stats:", 1)[1]) for l in r.stderr.splitlines() if l.startswith("tspgpu-stats:")]
+                nn_ = 1002 if key.startswith("pr1002") else 18512
+                row = {"rc": r.returncode, "stdout": r.stdout.strip()[:80], "process_wall_s": wall}
+                if st:
+                    row.update(st[-1])
+                    row["evals_per_s"] = st[-1]["sweeps"] * T.evals_per_sweep(nn_) / max(st[-1]["seconds"], 1e-9)
+                else:
+                    row["stderr_tail"] = r.stderr[-300:]
+                out[key] = row
+            out["pr1002_all_starts"]["golden_cost_266290"] = out["pr1002_all_starts"].get("stdout") == "Cost: 266290.00"
+            return out
+        host_c = guarded(host_c_leg)
+
+    out = {
+        "metric": "2-opt delta evals/sec/node (n=4096 EUC_2D, NN(0) tour to 2-opt local optimum)",
+        "value": tot_sweeps * evals / tmax,
+        "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * tmax / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {T.ELEM_U16: "uint16 costs, int32 deltas", T.ELEM_I32: "int32", T.ELEM_F64: "f64"}[info["elem"]],
+        "data": "synthetic",
+        "config": {"workload": f"uniform-random EUC_2D n={n} (reference generator -n {n} -seed {seed}), "
+                               f"cost matrix resident in HBM, NN(start=rank) tour -> best-improvement 2-opt "
+                               f"to the local optimum; one step = one full local search",
+                   "n": n, "seed": seed, "evals_per_sweep": evals,
+                   "sweeps_per_step_rank0": my_sweeps // max(args.steps, 1),
+                   "matrix_elem": {T.ELEM_U16: "uint16 exact copy", T.ELEM_I32: "int32 exact copy", T.ELEM_F64: "f64"}[info["elem"]],
+                   "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
+                   "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
+                   "parallelism": f"multistart-shard{world}"},
+        "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
+        "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost, "parity": gate,
+        "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
+        "roofline": roof, "roofline_build": broof, "cpu_baseline": base, "other_matrix_storage": other,
+        "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
+    }
+    if base and "value" in base:
+        out["gpu_over_cpu"] = out["value"] / base["value"]
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

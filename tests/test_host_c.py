@@ -189,7 +189,8 @@ def test_bench_line_contract():
     the parity gate (final cost of the headline workload)"""
     import json, subprocess, sys
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-sweeps", "3",
-                          "--no-other", "--batch-starts", "0"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--no-other", "--batch-starts", "0", "--no-sizes", "--no-otf", "--no-cpu-multistart", "--no-host-c"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -202,6 +203,12 @@ def test_bench_line_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "GB/s"
     assert d["final_cost_rank0"] == 488522.0 and d["config"]["sweeps_per_step_rank0"] == 609
+    assert d["parity"]["ok"] is True and d["parity"]["final_fnv"]          # the in-run gate against the committed golden
+    assert r["traffic"] is None and "traffic_from_committed_profile" in r   # PMC bytes are not measured by the run itself
+    b = d["roofline_build"]
+    assert b["bound"] == "hbm" and b["kernel"].startswith("k_build_costs") and abs(b["frac"] - b["achieved"] / 8000.0) < 1e-9
+    for k in ("sizes", "otf", "cpu_multistart_baseline", "host_c_path", "other_matrix_storage", "multistart_batch"):
+        assert k in d
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
 

@@ -30,7 +30,7 @@ def main():
         path = os.path.join(root, f"{rnd}_pmc_sq_{elem}_n{n}.csv")
         with open(path, "w") as out:
             out.write(f"# {rnd}: rocprofv3 --pmc passes (8 SQ counters per pass, separate runs, no tracing) of\n"
-                      f"#   python3 bench.py --n {n} --elem {elem} --steps 1 --warmup 0 --cpu-sweeps 0 --no-other --batch-starts 0 --no-sizes\n"
+                      f"#   python3 bench.py --n {n} --elem {elem} --steps 1 --warmup 0 --lean\n"
                       "# mean per LIVE launch (launches whose value is below 10 % of the kernel's maximum for that counter are the\n"
                       "# early exits of a finished search); SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are quad-cycles summed over waves\n"
                       "kernel,counter,launches,live,mean_live,max\n")

@@ -60,6 +60,7 @@ SIGNATURES = {
     "tspgpu_multi_ctx": (_ctx, [_ctx, C.c_int]),
     "tspgpu_multi_info": (C.c_double, [_ctx, C.c_int]),
     "tspgpu_multi_set_option": (C.c_int, [_ctx, C.c_int, C.c_long]),
+    "tspgpu_multi_prepare": (C.c_int, [_ctx]),
     "tspgpu_multi_set_points": (C.c_int, [_ctx, _dp, C.c_int, C.c_int]),
     "tspgpu_multi_build_costs": (C.c_int, [_ctx]),
     "tspgpu_multi_multistart_nn_2opt": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pl]),

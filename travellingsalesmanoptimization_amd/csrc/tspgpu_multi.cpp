@@ -203,15 +203,18 @@ struct Local {           // one device's result
 // (-1: no device found anything).
 int exchange(tspgpu_multi *m, std::vector<Local> &L, int n, int *best_path, double *best_cost, long *best_pos, int *owner)
 {
-    const double t0 = now_s();
     const int G = m->G;
     const int kind = exchange_kind(m);
     m->last_kind = kind;
     int win = -1;
     if (kind == 2) {
-        int rc = ensure_comm(m);
+        int rc = ensure_comm(m);           // (tspgpu_multi_prepare does this ahead of the timed region)
         if (rc) return rc;
         if ((rc = ensure_buffers(m, n))) return rc;
+    }
+    const double t0 = now_s();
+    if (kind == 2) {
+        int rc;
         std::vector<long long> key(G);
         bool packs = true;
         for (int i = 0; i < G; i++) {
@@ -356,6 +359,12 @@ int tspgpu_multi_set_option(tspgpu_multi *m, int option, long value)
         if (rc) return mfail(m, rc, "device %d: %s", m->dev[i], tspgpu_last_error(m->ctx[i]));
     }
     return E_OK;
+}
+
+int tspgpu_multi_prepare(tspgpu_multi *m)
+{
+    if (!m) return E_INVALID;
+    return exchange_kind(m) == 2 ? ensure_comm(m) : (int)E_OK;
 }
 
 int tspgpu_multi_set_points(tspgpu_multi *m, const double *xy, int n, int edge_weight_type)

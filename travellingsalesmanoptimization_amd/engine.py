@@ -257,6 +257,10 @@ class MultiEngine:
     def build_costs(self):
         self._ck(self.L.tspgpu_multi_build_costs(self.m))
 
+    def prepare(self):
+        """create the RCCL communicator ahead of the first exchange (outside any timed region)"""
+        self._ck(self.L.tspgpu_multi_prepare(self.m))
+
     def multistart_nn_2opt(self, starts=None, time_left_s=-1.0):
         """h_greedy_2opt (heuristics.c:74-116) over every device -> dict."""
         p, m, keep = Engine._starts(starts, self.n)

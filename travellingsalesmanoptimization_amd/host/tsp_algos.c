@@ -119,6 +119,19 @@ static tspgpu_ctx *ctx_for(double *costs)
 
 static ERROR_CODE from_rc(int rc) { return (ERROR_CODE)rc; }
 
+/* TSP_GPU_STATS=1: one JSON line per multi-start call on stderr (what bench.py's C-path leg parses) */
+static void multi_stats(const char *what, struct tspgpu_multi *m, int starts, long sweeps, double seconds, double cost)
+{
+    const char *on = getenv("TSP_GPU_STATS");
+    if (!on || !atoi(on)) return;
+    static const char *kinds[] = {"none", "host", "rccl"};
+    const int kind = m ? (int)tspgpu_multi_info(m, 2) : 0;
+    fprintf(stderr, "tspgpu-stats: {\"call\": \"%s\", \"devices\": %d, \"exchange\": \"%s\", \"starts\": %d, \"sweeps\": %ld, "
+                    "\"seconds\": %.6f, \"solve_s\": %.6f, \"exchange_s\": %.6f, \"rccl_init_s\": %.6f, \"best_cost\": %.2f}\n",
+            what, m ? tspgpu_multi_devices(m) : 1, kinds[kind < 0 || kind > 2 ? 0 : kind], starts, sweeps, seconds,
+            m ? tspgpu_multi_info(m, 5) : seconds, m ? tspgpu_multi_info(m, 4) : 0.0, m ? tspgpu_multi_info(m, 3) : 0.0, cost);
+}
+
 /* ===================================================================== refinment.c */
 
 /* refinment.c:3-37.  Cost recompute, sweep loop and stop rule run on the device
@@ -215,12 +228,16 @@ ERROR_CODE h_Greedy_iterative(void)
     if (past_deadline()) return DEADLINE_EXCEEDED;
     tspgpu_ctx *g = tsp_gpu();
     if (!g) return UNAVAILABLE;
+    struct tspgpu_multi *m = tsp_gpu_multi();
     tsp_solution s;
     tsp_init_solution(tsp_inst.nnodes, &s);
     int start = -1, done = 0;
-    int rc = tspgpu_nn_all_timed(g, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &done);
+    const double t0 = utils_timeelapsed(&tsp_inst.c);
+    int rc = m ? tspgpu_multi_nn_all(m, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &done)
+               : tspgpu_nn_all_timed(g, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &done);
+    multi_stats("h_Greedy_iterative", m, tsp_inst.nnodes, 0, utils_timeelapsed(&tsp_inst.c) - t0, s.cost);
     ERROR_CODE e = from_rc(rc);
-    if (rc && rc != DEADLINE_EXCEEDED) log_error("tspgpu_nn_all: %s", tspgpu_last_error(g));
+    if (rc && rc != DEADLINE_EXCEEDED) log_error("tspgpu_nn_all: %s", m ? tspgpu_multi_last_error(m) : tspgpu_last_error(g));
     else if (start >= 0 && s.cost < tsp_inst.best_solution.cost) {
         log_info("found new best, node %d", start);
         tsp_inst.starting_node = start;
@@ -244,10 +261,15 @@ ERROR_CODE h_greedy_2opt(void)
     tsp_init_solution(tsp_inst.nnodes, &s);
     int start = -1;
     long sweeps = 0;
-    int rc = tspgpu_multistart_nn_2opt(g, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &sweeps, NULL, NULL);
+    /* several devices (TSP_GPU_DEVICES): start i on device i mod G, one RCCL MIN all-reduce + one broadcast */
+    struct tspgpu_multi *m = tsp_gpu_multi();
+    const double t0 = utils_timeelapsed(&tsp_inst.c);
+    int rc = m ? tspgpu_multi_multistart_nn_2opt(m, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &sweeps)
+               : tspgpu_multistart_nn_2opt(g, NULL, tsp_inst.nnodes, time_left(), s.path, &s.cost, &start, &sweeps, NULL, NULL);
+    multi_stats("h_greedy_2opt", m, tsp_inst.nnodes, sweeps, utils_timeelapsed(&tsp_inst.c) - t0, s.cost);
     ERROR_CODE e = from_rc(rc);
     if (rc != 0 && rc != DEADLINE_EXCEEDED) {
-        log_error("tspgpu_multistart_nn_2opt: %s", tspgpu_last_error(g));
+        log_error("tspgpu_multistart_nn_2opt: %s", m ? tspgpu_multi_last_error(m) : tspgpu_last_error(g));
     } else {
         ERROR_CODE u = tsp_update_best_solution(&s);
         if (!err_ok(u)) log_error("code %d : Error in 2opt solution update", u);

@@ -18,10 +18,47 @@ int tsp_edge_weight_kind = TSPGPU_EUC_2D;
 bool tsp_matrix_free = false;
 
 static struct tspgpu_ctx *g_ctx = NULL;
+static struct tspgpu_multi *g_multi = NULL;    /* set when TSP_GPU_DEVICES names the devices; owns g_ctx then */
+
+/* TSP_GPU_DEVICES="0,1,2,3": the devices the multi-start loops (h_greedy_2opt, h_Greedy_iterative) shard over.
+ * Unset: one device, TSP_GPU_DEVICE (default 0).  A device may be listed twice (two contexts on one GPU). */
+static int device_list(int *out, int cap)
+{
+    const char *s = getenv("TSP_GPU_DEVICES");
+    int k = 0;
+    if (!s) return 0;
+    while (*s && k < cap) {
+        char *end;
+        const long v = strtol(s, &end, 10);
+        if (end == s) break;
+        out[k++] = (int)v;
+        s = end;
+        while (*s == ',' || *s == ' ') s++;
+    }
+    return k;
+}
 
 struct tspgpu_ctx *tsp_gpu(void)
 {
     if (!g_ctx) {
+        int devs[64];
+        const int nd = device_list(devs, 64);
+        if (nd > 0) {
+            int rc = tspgpu_multi_create(devs, nd, &g_multi);
+            if (rc != 0) {
+                log_fatal("TSP_GPU_DEVICES: tspgpu_multi_create over %d device(s) -> %d; there is no CPU fallback", nd, rc);
+                g_multi = NULL;
+                return NULL;
+            }
+            const char *ex = getenv("TSP_GPU_EXCHANGE");     /* "rccl" | "host"; unset = automatic */
+            if (ex && tspgpu_multi_set_option(g_multi, TSPGPU_MOPT_EXCHANGE, !strcmp(ex, "rccl") ? 2 : !strcmp(ex, "host") ? 1 : 0) != 0) {
+                log_fatal("TSP_GPU_EXCHANGE=%s: %s", ex, tspgpu_multi_last_error(g_multi));
+                tspgpu_multi_destroy(g_multi); g_multi = NULL;
+                return NULL;
+            }
+            g_ctx = tspgpu_multi_ctx(g_multi, 0);
+            return g_ctx;
+        }
         const char *dev = getenv("TSP_GPU_DEVICE");
         tspgpu_ctx *c = NULL;
         int rc = tspgpu_create(dev ? atoi(dev) : 0, &c);
@@ -34,10 +71,19 @@ struct tspgpu_ctx *tsp_gpu(void)
     return g_ctx;
 }
 
+/* the multi-device handle, or NULL when the run is on one device */
+struct tspgpu_multi *tsp_gpu_multi(void)
+{
+    tsp_gpu();
+    return g_multi;
+}
+
 void tsp_gpu_release(void)
 {
     tsp_gpu_release_threads();          /* contexts of caller-matrix threads that are still alive (tsp_algos.c) */
-    if (g_ctx) tspgpu_destroy(g_ctx);
+    if (g_multi) tspgpu_multi_destroy(g_multi);     /* owns every device's context, g_ctx included */
+    else if (g_ctx) tspgpu_destroy(g_ctx);
+    g_multi = NULL;
     g_ctx = NULL;
 }
 
@@ -137,9 +183,8 @@ ERROR_CODE tsp_compute_costs(void)
     if (tsp_inst.nnodes <= 0) { log_fatal("computing costs of empty graph"); tsp_handlefatal(); }
     struct tspgpu_ctx *g = tsp_gpu();
     if (!g) return UNAVAILABLE;
+    struct tspgpu_multi *m = tsp_gpu_multi();
     const size_t n = (size_t)tsp_inst.nnodes;
-    int rc = tspgpu_set_points(g, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind);
-    if (rc) { log_error("tspgpu_set_points: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
     free(tsp_inst.costs);
     tsp_inst.costs = NULL;
     /* Matrix-free above 32 768 nodes (8 GB of doubles on the host; the reference overflows int
@@ -147,6 +192,26 @@ ERROR_CODE tsp_compute_costs(void)
      * device recomputes weights from the coordinates and tsp_inst.costs stays NULL. */
     const char *mf = getenv("TSP_MATRIX_FREE");
     tsp_matrix_free = mf ? atoi(mf) != 0 : n > 32768;   /* an explicit 0 keeps the matrix at any size */
+    int rc;
+    if (m) {
+        /* several devices: each builds its own matrix from the 16n-byte coordinate array (never shipped) */
+        if ((rc = tspgpu_multi_set_option(m, TSPGPU_OPT_MATRIX_FREE, tsp_matrix_free ? 1 : 0)) ||
+            (rc = tspgpu_multi_set_points(m, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind)) ||
+            (rc = tspgpu_multi_build_costs(m))) {
+            log_error("multi-device cost build: %s", tspgpu_multi_last_error(m));
+            return (ERROR_CODE)rc;
+        }
+        /* the RCCL communicator, if the exchange will use one: before the clock starts (main.c:177) */
+        if ((rc = tspgpu_multi_prepare(m))) { log_error("tspgpu_multi_prepare: %s", tspgpu_multi_last_error(m)); return (ERROR_CODE)rc; }
+        if (tsp_matrix_free) return T_OK;
+        tsp_inst.costs = (double *)malloc(n * n * sizeof(double));
+        if (!tsp_inst.costs) return RESOURCE_EXHAUSTED;
+        rc = tspgpu_get_costs(g, tsp_inst.costs);
+        if (rc) { log_error("tspgpu_get_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
+        return T_OK;
+    }
+    rc = tspgpu_set_points(g, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind);
+    if (rc) { log_error("tspgpu_set_points: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
     if (tsp_matrix_free) {
         tspgpu_set_option(g, TSPGPU_OPT_MATRIX_FREE, 1);
         rc = tspgpu_build_costs(g, NULL);

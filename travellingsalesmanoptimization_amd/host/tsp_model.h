@@ -169,6 +169,11 @@ extern bool tsp_matrix_free;
 struct tspgpu_ctx;
 struct tspgpu_ctx *tsp_gpu(void);
 void tsp_gpu_release(void);
+/* TSP_GPU_DEVICES="0,1,...": the multi-start loops (h_greedy_2opt, h_Greedy_iterative) shard their start nodes over
+ * these devices (include/tspgpu.h, tspgpu_multi_*: one RCCL MIN all-reduce + one broadcast per call); NULL otherwise.
+ * TSP_GPU_EXCHANGE=rccl|host overrides the automatic choice; TSP_GPU_STATS=1 prints one JSON line per call on stderr. */
+struct tspgpu_multi;
+struct tspgpu_multi *tsp_gpu_multi(void);
 /* caller-matrix calls (h_Greedy_2opt_mod_costs from CPLEX callback threads, cplex_model.c:1176-1258) run in a
  * device context private to the calling thread; it is destroyed when the thread exits.  Live count / early release: */
 int tsp_gpu_thread_contexts(void);
