@@ -533,7 +533,7 @@ def main():
                 else:
                     row["stderr_tail"] = r.stderr[-300:]
                 out[key] = row
-            out["pr1002_all_starts"]["golden_cost_266290"] = out["pr1002_all_starts"].get("stdout") == "Cost: 266290.00"
+            out["pr1002_all_starts"]["golden_cost_266290"] = out["pr1002_all_starts"].get("stdout") == "Cost: 266290.00"   # whole stdout
             return out
         host_c = guarded(host_c_leg)
 

@@ -117,6 +117,85 @@ def test_nn_tour(eng, T, O, instances, name, elem):
     assert ei.value.code == 14  # UNAVAILABLE, heuristics.c:223-226
 
 
+def _nn_instance(name, instances):
+    if name == "clusters":        # 24 tight clusters of non-integer points: cells far above the average occupancy
+        r = np.random.RandomState(11)
+        cen = r.uniform(-4000, 4000, size=(24, 2))
+        return np.ascontiguousarray(np.concatenate([c + r.normal(0, 3.0, size=(40, 2)) for c in cen]))
+    if name == "collinear":       # a degenerate bounding box (height 0) with repeated spacings
+        x = np.arange(500, dtype=np.float64) * 3.7
+        return np.ascontiguousarray(np.stack([np.random.RandomState(2).permutation(x), np.full(500, 5.0)], -1))
+    if name == "heavy_dups":      # 300 copies of one point: the grid cannot spread them (falls back to the matrix kernel)
+        r = np.random.RandomState(4)
+        return np.ascontiguousarray(np.concatenate([np.tile([[17.0, -3.0]], (300, 1)), r.randint(-50, 50, size=(200, 2)).astype(np.float64)]))
+    if name == "int1e6":
+        return np.random.RandomState(3).randint(0, 1500000, size=(700, 2)).astype(np.float64)
+    if name == "frac":
+        return np.random.RandomState(4).uniform(-5000, 5000, size=(600, 2))
+    if name in ("grid20", "grid32x40", "dups"):
+        return _grid_instance(name)
+    return instances(name)[0]
+
+
+@pytest.mark.parametrize("kind", ["EUC_2D", "ATT", "CEIL_2D"])
+@pytest.mark.parametrize("inst", ["berlin52", "kroA100", "pr1002", "n1024_s1", "n300_s5", "n257_s2", "n256_s9", "n40_s1", "grid20",
+                                  "grid32x40", "dups", "clusters", "collinear", "heavy_dups", "int1e6", "frac"])
+def test_nn_grid_kernel_is_exact(eng, T, O, instances, inst, kind):
+    """the grid NN (k_nn_grid: coordinates through a uniform grid, one wave per start) against the oracle's
+    matrix NN -- lowest weight, ties to the lowest node index (heuristics.c:253-263) -- for every weight kind, with
+    and without a matrix, next to the matrix / strided kernels it replaces; lattices, duplicates, clusters, a
+    degenerate bounding box, sizes around the 256-node register tail"""
+    xy = _nn_instance(inst, instances)
+    n = len(xy)
+    k = getattr(O, kind)
+    c = O.cost_matrix(xy, k)
+    want_all = O.nn_all(c)
+    try:
+        for mf in (2, 1):
+            eng.set_option(T.OPT_MATRIX_FREE, mf); eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+            eng.set_points(xy, k); eng.build_costs()
+            for nnk in (0, 1):
+                eng.set_option(T.OPT_NN_KERNEL, nnk)
+                info = eng.info()
+                assert (info["nn_grid"] > 0) == (nnk == 0 and inst != "heavy_dups"), info
+                for start in sorted({0, 1, n // 2, n - 1}):
+                    succ, cost = eng.nn_tour(start)
+                    osucc, ocost = O.nn_tour(c, start)
+                    assert cost == ocost and np.array_equal(succ, osucc), (mf, nnk, start)
+                best, bcost, bstart = eng.nn_all()
+                assert (bcost, bstart) == (want_all[1], want_all[2]) and np.array_equal(best, want_all[0])
+    finally:
+        eng.set_option(T.OPT_NN_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+
+
+def test_nn_grid_large_instances(eng, T, O, golden):
+    """the grid NN at the sizes it was written for: n=4096 / 16384 uniform (bench), usa13509 (non-integer coordinates in
+    the millions), d18512 and pla85900 (CEIL_2D, matrix-free) against the goldens / the oracle"""
+    import json, os
+    for n, seed in ((4096, 123), (16384, 123)):
+        xy = O.random_points(n, seed)
+        eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+        eng.set_points(xy); eng.build_costs()
+        assert eng.info()["nn_grid"] > 0
+        for start in (0, n - 1):
+            succ, cost = eng.nn_tour(start)
+            osucc, ocost = O.nn_tour_xy(xy, O.EUC_2D, start)
+            assert cost == ocost and np.array_equal(succ, osucc)
+    for name in ("usa13509", "d18512"):
+        xy, _ = O.read_tsplib(data_path(name))
+        eng.set_points(xy); eng.build_costs()
+        assert eng.info()["nn_grid"] > 0
+        g = golden["instances"][name]["two_opt"]
+        succ, cost = eng.nn_tour(0)
+        assert cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_large.json")))["pla85900"]
+    xy, _ = O.read_tsplib(data_path("pla85900"))
+    eng.set_points(xy, O.CEIL_2D); eng.build_costs()
+    assert eng.info()["nn_grid"] > 0 and eng.info()["matrix_free"] == 1
+    succ, cost = eng.nn_tour(0)
+    assert cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+
+
 def test_nn_all_golden(eng, T, O, instances, golden):
     for key in ["berlin52", "kroA100", "pr1002", "n1000_s123"]:
         setup(eng, T, O, instances, key, 0)

@@ -120,7 +120,7 @@ def test_binary_multi_device_paths(golden, name):
                             ({"TSP_GPU_DEVICES": "0,0"}, "host", 2), ({"TSP_GPU_DEVICES": "0"}, "none", 1)]:
         env = dict(env, TSP_GPU_STATS="1")
         rc, out, err = run_q("-f", f, "-alg", "2OPT_GREEDY", env=env)
-        assert rc == 0 and out == "Cost: %.2f" % g2, err
+        assert rc == 0 and out == "Cost: %.2f" % g2, (out, err)     # stdout is the contract: nothing else on it (RCCL's banner goes to stderr)
         st = stats(err)
         assert len(st) == 1 and st[0]["call"] == "h_greedy_2opt" and st[0]["exchange"] == kind and st[0]["devices"] == ndev
         assert st[0]["best_cost"] == g2 and st[0]["sweeps"] > 0 and (st[0]["rccl_init_s"] > 0) == (kind == "rccl")

@@ -555,6 +555,223 @@ __global__ void __launch_bounds__(1024) k_nn_vec(Tours S, const T *__restrict__ 
     }
 }
 
+// One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
+// correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
+// and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
+// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
+// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
+// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
+constexpr int KIND_CEIL_INT = 3;
+template <int KIND>
+__device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
+{
+    const double dx = bx - ax, dy = by - ay;
+    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
+    if constexpr (KIND == TSPGPU_EUC_2D) {
+        const float x = (float)sq;
+        const float r = __builtin_amdgcn_sqrtf(x);
+        const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+        const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+        float c = 0.0f >= em ? rm : r;
+        c = 0.0f < ep ? rp : c;
+        return (int)((double)c + 0.5);
+    } else if constexpr (KIND == KIND_CEIL_INT) {
+        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
+        k = k * k < sq ? k + 1.0 : k;
+        k = k * k < sq ? k + 1.0 : k;
+        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
+        return (int)k;
+    } else return (int)edge_weight(ax, ay, bx, by, KIND);
+}
+
+
+// ---------------------------------------------------------------------------
+// K6, third form: nearest-neighbour tour from the COORDINATES through a uniform grid -- for every
+// instance whose weights come from its points (EUC_2D / ATT / CEIL_2D, matrix or matrix-free).  The
+// matrix kernels above pay one dependent row fetch + one workgroup barrier per step (1.6 us at n = 4096,
+// 3.2 us at 16 384: SURVEY 8f rank 1, the seed tour had become 40 % of a single search); here a step is
+// a handful of LDS reads and ~100 vector instructions in ONE wave, no barrier, no matrix traffic.
+//
+// Exactness.  Every weight kind is a monotone function of the squared distance as the kernels compute it
+// (conversion, root, rounding are all monotone), so the reference's pick -- min over unvisited i of
+// c[cur][i], strict <, i ascending (heuristics.c:253-263) = min of the key (weight << 32 | i) -- lies
+// among the points closer than (best weight so far) + rounding.  The points are bucketed into G x G cells
+// (host, tspgpu_set_points; cells row-major, points sorted by cell, so the cells cx-R..cx+R of one grid row
+// are ONE contiguous range of sorted positions).  A step examines the (2R+1)^2 cells around the current
+// node, R = 2 first, with the exact weight (edge_w: the arithmetic of k_build_costs); every point
+// outside is at least R cells away, so once weight(R * cell - eps) > best the pick is final; else the
+// square grows (only its new frame is examined).  The last 256 unvisited nodes move into registers
+// (4 per lane): the end of an NN walk, where the nearest unvisited node is far away, costs no expansion.
+// ---------------------------------------------------------------------------
+struct GridArgs {
+    Tours S;
+    int n, slot0;
+    const int *starts;
+    const double2 *gxy;      // [n] points, sorted by cell
+    const int *gidx;         // [n] sorted position -> node
+    const int *gpos;         // [n] node -> sorted position
+    const int *cstart;       // [G*G + 1] first sorted position of every cell
+    int G;
+    double x0, y0, cell, inv_cell, eps;
+    int lds_pts;             // points + node ids copied into LDS (single tours; batches read them through L2)
+    int lds_cstart;          // cell starts copied into LDS
+};
+
+constexpr int NN_TAIL = 256;
+
+template <int KIND>
+__global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int n = A.n, G = A.G, lane = threadIdx.x;
+    const int t = A.slot0 + blockIdx.x;
+    const int start = A.starts[blockIdx.x];
+    int *ord = A.S.ord + (size_t)t * n;
+    // LDS: visited bits | tail list | (cell starts) | (points, node ids)
+    const int nwords = (n + 31) >> 5;
+    unsigned *vis = reinterpret_cast<unsigned *>(smem);
+    int *tail = reinterpret_cast<int *>(vis + ((nwords + 3) & ~3));
+    int *cs_l = tail + NN_TAIL;
+    const int ncs = G * G + 1;
+    double2 *pts_l = reinterpret_cast<double2 *>(cs_l + (A.lds_cstart ? ((ncs + 3) & ~3) : 0));
+    int *idx_l = reinterpret_cast<int *>(pts_l + (A.lds_pts ? n : 0));
+    for (int w = lane; w < nwords; w += 64) vis[w] = 0;
+    if (A.lds_cstart) for (int i = lane; i < ncs; i += 64) cs_l[i] = A.cstart[i];
+    if (A.lds_pts) for (int i = lane; i < n; i += 64) { pts_l[i] = A.gxy[i]; idx_l[i] = A.gidx[i]; }
+    __syncthreads();
+    const int *cstart = A.lds_cstart ? cs_l : A.cstart;
+    const double2 *pts = A.lds_pts ? pts_l : A.gxy;
+    const int *gidx = A.lds_pts ? idx_l : A.gidx;
+
+    int cur = A.gpos[start];                       // sorted position of the current node (wave-uniform)
+    double2 P = A.gxy[cur];                        // its coordinates (wave-uniform)
+    const double2 P0 = P;
+    if (lane == 0) { ord[0] = start; vis[cur >> 5] |= 1u << (cur & 31); }
+    __syncthreads();
+    double total = 0;
+    int step = 1;
+    const int grid_steps = n - 1 > NN_TAIL ? n - 1 - NN_TAIL : 0;     // steps taken through the grid
+
+    auto wave_min = [&](u64 k) __attribute__((always_inline)) {
+        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(k, off); k = o < k ? o : k; }
+        return k;
+    };
+
+    for (; step <= grid_steps; step++) {
+        const int cx = min(G - 1, max(0, (int)((P.x - A.x0) * A.inv_cell)));
+        const int cy = min(G - 1, max(0, (int)((P.y - A.y0) * A.inv_cell)));
+        u64 best = KEY_NONE;                        // lane's best candidate: weight << 32 | node ...
+        int bestp = 0;                              // ... its sorted position and coordinates
+        double2 bestQ = make_double2(0, 0);
+        auto cand = [&](int p) __attribute__((always_inline)) {
+            if ((vis[p >> 5] >> (p & 31)) & 1u) return;
+            const double2 Q = pts[p];
+            const u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q.x, Q.y) << 32) | (unsigned)gidx[p];
+            if (key < best) { best = key; bestp = p; bestQ = Q; }
+        };
+        int Rin = -1, R = 2;                        // cells within Rin of (cx, cy) are done
+        u64 win;
+        for (;;) {
+            const int ylo = max(0, cy - R), yhi = min(G - 1, cy + R);
+            const int xlo = max(0, cx - R), xhi = min(G - 1, cx + R);
+            const int nrows = yhi - ylo + 1;
+            const int L = nrows >= 64 ? 1 : 64 / nrows;           // lanes per grid row
+            const int rpp = 64 / L;                               // grid rows per pass
+            for (int r0 = 0; r0 < nrows; r0 += rpp) {
+                const int jl = lane / L, k = lane - jl * L, j = r0 + jl;
+                if (jl < rpp && j < nrows) {
+                    const int y = ylo + j;
+                    const int rowbase = y * G;
+                    // new cells of this row: the whole span outside the inner square's rows, its two flanks inside
+                    const bool inner = Rin >= 0 && y >= cy - Rin && y <= cy + Rin;
+                    const int s1 = cstart[rowbase + xlo];
+                    int e1, s2 = 0, e2 = 0;
+                    if (!inner) e1 = cstart[rowbase + xhi + 1];
+                    else {
+                        const int ixlo = max(0, cx - Rin), ixhi = min(G - 1, cx + Rin);
+                        e1 = cstart[rowbase + ixlo];
+                        s2 = cstart[rowbase + ixhi + 1]; e2 = cstart[rowbase + xhi + 1];
+                    }
+                    for (int p = s1 + k; p < e1; p += L) cand(p);
+                    for (int p = s2 + k; p < e2; p += L) cand(p);
+                }
+            }
+            win = wave_min(best);
+            const bool whole = xlo == 0 && ylo == 0 && xhi == G - 1 && yhi == G - 1;
+            if (win != KEY_NONE) {
+                // every point not examined yet is at least R cells away from the current node
+                const double lb = fmax(0.0, (double)R * A.cell - A.eps);
+                if (whole || (u64)(unsigned)edge_w<KIND>(0.0, 0.0, lb, 0.0) > (win >> 32)) break;
+            } else if (whole) break;                              // (cannot happen: unvisited nodes remain)
+            Rin = R;
+            R += max(2, R >> 1);
+        }
+        // the lane that holds the winner (node ids are unique) hands over its position and coordinates
+        const int src = __ffsll((unsigned long long)__ballot(best == win)) - 1;
+        cur = __shfl(bestp, src);
+        P.x = __shfl(bestQ.x, src); P.y = __shfl(bestQ.y, src);
+        total += (double)(unsigned)(win >> 32);
+        if (lane == 0) { ord[step] = (int)(win & 0xffffffffu); vis[cur >> 5] |= 1u << (cur & 31); }
+        __syncthreads();
+    }
+
+    // ---- the last <= NN_TAIL unvisited nodes: in registers, four per lane
+    {
+        const int remaining = n - step;
+        // compact list of the unvisited sorted positions (ascending), by a wave prefix sum over the visited words
+        int cntl = 0;
+        const int wpl = (nwords + 63) / 64;                        // words per lane (contiguous block)
+        const int w0 = min(nwords, lane * wpl), w1 = min(nwords, w0 + wpl);
+        for (int w = w0; w < w1; w++) {
+            unsigned f = ~vis[w];
+            if (w == nwords - 1 && (n & 31)) f &= (1u << (n & 31)) - 1u;
+            cntl += __popc(f);
+        }
+        int pre = cntl;
+        for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(pre, off); if (lane >= off) pre += o; }
+        int at = pre - cntl;
+        for (int w = w0; w < w1; w++) {
+            unsigned f = ~vis[w];
+            if (w == nwords - 1 && (n & 31)) f &= (1u << (n & 31)) - 1u;
+            while (f) { const int b = __ffs(f) - 1; f &= f - 1; if (at < NN_TAIL) tail[at] = w * 32 + b; at++; }
+        }
+        __syncthreads();
+        constexpr int U = NN_TAIL / 64;
+        double2 Q[U];
+        int qid[U];
+        unsigned alive = 0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = u * 64 + lane;
+            Q[u] = make_double2(0, 0); qid[u] = -1;
+            if (e < remaining) { const int p = tail[e]; Q[u] = A.gxy[p]; qid[u] = A.gidx[p]; alive |= 1u << u; }
+        }
+        for (; step < n; step++) {
+            u64 best = KEY_NONE;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q[u].x, Q[u].y) << 32) | (unsigned)qid[u];
+                best = (((alive >> u) & 1u) && key < best) ? key : best;
+            }
+            const u64 win = wave_min(best);
+            const int nxt = (int)(win & 0xffffffffu);
+            total += (double)(unsigned)(win >> 32);
+            double px = 0, py = 0;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (((alive >> u) & 1u) && qid[u] == nxt) { alive &= ~(1u << u); px = Q[u].x; py = Q[u].y; }
+            const int src = __ffsll((unsigned long long)__ballot(best == win)) - 1;
+            P.x = __shfl(px, src); P.y = __shfl(py, src);
+            if (lane == 0) ord[step] = nxt;
+        }
+        if (lane == 0) {
+            total += (double)edge_w<KIND>(P.x, P.y, P0.x, P0.y);      // closing edge, heuristics.c:281
+            A.S.cost[t] = total;
+            A.S.status[t] = 0;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // sweep arguments
 // ---------------------------------------------------------------------------
@@ -1727,35 +1944,6 @@ __global__ void __launch_bounds__(256) k_gather_spts(Tours S, int n, int slot0, 
     spts[(size_t)blockIdx.y * n + b] = pts[S.succ[(size_t)t * n + b]];
 }
 
-// One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
-// correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
-// and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
-// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
-// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
-// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
-constexpr int KIND_CEIL_INT = 3;
-template <int KIND>
-__device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
-{
-    const double dx = bx - ax, dy = by - ay;
-    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
-    if constexpr (KIND == TSPGPU_EUC_2D) {
-        const float x = (float)sq;
-        const float r = __builtin_amdgcn_sqrtf(x);
-        const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
-        const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
-        float c = 0.0f >= em ? rm : r;
-        c = 0.0f < ep ? rp : c;
-        return (int)((double)c + 0.5);
-    } else if constexpr (KIND == KIND_CEIL_INT) {
-        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
-        k = k * k < sq ? k + 1.0 : k;
-        k = k * k < sq ? k + 1.0 : k;
-        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
-        return (int)k;
-    } else return (int)edge_weight(ax, ay, bx, by, KIND);
-}
-
 // ---------------------------------------------------------------------------
 // Matrix-free sweep, second form (costs below 2^25, n < 131 072): a thread holds FOUR
 // consecutive b's (their points, the points of their successors, c[b][succ b]: 16-byte loads),
@@ -2220,6 +2408,11 @@ struct tspgpu_ctx {
     bool otf = false;        // matrix-free: weights recomputed from d_pts
     int opt_otf = 0;         // 0 auto, 1 force matrix-free, 2 never
     double2 *d_spts = nullptr; size_t spts_cap = 0;
+    // uniform grid over the points for the grid NN (k_nn_grid): built on the host in tspgpu_set_points
+    double2 *d_gxy = nullptr; int *d_gidx = nullptr, *d_gpos = nullptr, *d_cstart = nullptr;
+    int grid_G = 0, grid_max_occ = 0; bool grid_ok = false;
+    double grid_x0 = 0, grid_y0 = 0, grid_cell = 1, grid_inv = 0, grid_eps = 0;
+    int opt_nn = 0;          // 0 auto, 1 matrix / strided kernels, 2 grid kernel
     double cost_bound = 0;   // upper bound of any entry the uploaded points can produce
     bool int_coords = false; // every coordinate an integer below 2^25 in magnitude
     int *d_flags = nullptr;
@@ -2316,6 +2509,14 @@ static void free_tour_scratch(tspgpu_ctx *ctx)
     if (ctx->h_status) hipHostFree(ctx->h_status);
     if (ctx->h_costs) hipHostFree(ctx->h_costs);
     ctx->d_starts = ctx->d_caps = nullptr; ctx->h_status = nullptr; ctx->h_costs = nullptr;
+}
+
+static void free_grid(tspgpu_ctx *ctx)
+{
+    void *ptrs[] = {ctx->d_gxy, ctx->d_gidx, ctx->d_gpos, ctx->d_cstart};
+    for (void *p : ptrs) if (p) hipFree(p);
+    ctx->d_gxy = nullptr; ctx->d_gidx = ctx->d_gpos = ctx->d_cstart = nullptr;
+    ctx->grid_G = 0; ctx->grid_ok = false;
 }
 
 static void free_tours(tspgpu_ctx *ctx)
@@ -3074,6 +3275,67 @@ static int store_path(tspgpu_ctx *ctx, int slot, int *path, double *cost, double
     return E_OK;
 }
 
+// Uniform grid over the points (k_nn_grid): G x G square cells over the bounding box, about three points per cell
+// of the box's area (refined while a cell holds more than 32 and the cell table stays O(n)), cells row-major, points
+// counting-sorted by cell.  Instances the grid cannot spread (more than 256 points in one cell: massive duplicates)
+// keep the matrix / strided kernels.
+static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, double x1, double y0, double y1)
+{
+    free_grid(ctx);
+    const double w = x1 - x0, h = y1 - y0, extent = std::max(w, h);
+    if (!(extent >= 0) || !std::isfinite(extent)) return E_OK;        // NaN / inf coordinates: no grid
+    int G = 1;
+    double cell = 1.0;
+    std::vector<int> cid(n), cnt;
+    int max_occ = n;
+    if (extent > 0) {
+        const double area = std::max(w, extent * 1e-3) * std::max(h, extent * 1e-3);
+        cell = std::sqrt(area * 3.0 / n);
+        for (int round = 0; round < 4; round++) {
+            G = (int)std::min(4096.0, std::max(1.0, std::ceil(extent / cell)));
+            while ((double)G * G > 64.0 * n + 4096.0) G = G * 3 / 4;
+            cell = extent / G * (1.0 + 1e-12);
+            const double inv = 1.0 / cell;
+            cnt.assign((size_t)G * G, 0);
+            max_occ = 0;
+            for (int i = 0; i < n; i++) {
+                const int cx = std::min(G - 1, std::max(0, (int)((xy[2 * i] - x0) * inv)));
+                const int cy = std::min(G - 1, std::max(0, (int)((xy[2 * i + 1] - y0) * inv)));
+                cid[i] = cy * G + cx;
+                max_occ = std::max(max_occ, ++cnt[cid[i]]);
+            }
+            if (max_occ <= 32 || (double)(2 * G) * (2 * G) > 64.0 * n + 4096.0 || G >= 2048) break;
+            cell *= 0.5;
+        }
+    } else {
+        cnt.assign(1, n);
+        std::fill(cid.begin(), cid.end(), 0);
+    }
+    ctx->grid_max_occ = max_occ;
+    if (max_occ > 256) return E_OK;
+    const size_t C = (size_t)G * G;
+    std::vector<int> cstart(C + 1, 0), gidx(n), gpos(n);
+    for (size_t c = 0; c < C; c++) cstart[c + 1] = cstart[c] + cnt[c];
+    std::vector<int> fill(cstart.begin(), cstart.end() - 1);
+    for (int i = 0; i < n; i++) { const int p = fill[cid[i]]++; gidx[p] = i; gpos[i] = p; }   // node order inside a cell
+    std::vector<double> gxy((size_t)2 * n);
+    for (int p = 0; p < n; p++) { gxy[2 * p] = xy[2 * gidx[p]]; gxy[2 * p + 1] = xy[2 * gidx[p] + 1]; }
+    HIP_TRY(hipMalloc(&ctx->d_gxy, (size_t)n * sizeof(double2)));
+    HIP_TRY(hipMalloc(&ctx->d_gidx, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&ctx->d_gpos, (size_t)n * 4));
+    HIP_TRY(hipMalloc(&ctx->d_cstart, (C + 1) * 4));
+    HIP_TRY(hipMemcpy(ctx->d_gxy, gxy.data(), (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_gidx, gidx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->d_cstart, cstart.data(), (C + 1) * 4, hipMemcpyHostToDevice));
+    ctx->grid_G = G; ctx->grid_x0 = x0; ctx->grid_y0 = y0; ctx->grid_cell = cell; ctx->grid_inv = extent > 0 ? 1.0 / cell : 0.0;
+    ctx->grid_eps = 1e-7 * cell + 1e-9 * (std::fabs(x0) + std::fabs(x1) + std::fabs(y0) + std::fabs(y1) + extent);
+    ctx->grid_ok = true;
+    return E_OK;
+}
+
+template <int KIND> static const void *nn_grid_fn() { return (const void *)k_nn_grid<KIND>; }
+
 // NN tours from h_starts into ord[] / cost[] of slots [slot0, slot0+count).  The slots are NOT complete tour states
 // afterwards (init_slots derives pos / succ / edge costs); they are marked invalid here and valid again by the callers
 // that run init_slots.  Fails with INVALID_ARGUMENT when a tour could not be completed (an unvisited node without an
@@ -3087,7 +3349,29 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
     HIP_TRY(hipMemcpyAsync(ctx->d_starts, h_starts, (size_t)count * 4, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     bool launched = false;
-    if (ctx->d_mat && !ctx->otf) {
+    // weights that come from the points (built matrix or matrix-free, integer weights below 2^27): the grid kernel
+    if (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) {
+        GridArgs A;
+        A.S = ctx->S; A.n = n; A.slot0 = slot0; A.starts = ctx->d_starts;
+        A.gxy = ctx->d_gxy; A.gidx = ctx->d_gidx; A.gpos = ctx->d_gpos; A.cstart = ctx->d_cstart;
+        A.G = ctx->grid_G; A.x0 = ctx->grid_x0; A.y0 = ctx->grid_y0; A.cell = ctx->grid_cell; A.inv_cell = ctx->grid_inv;
+        A.eps = ctx->grid_eps;
+        const size_t nwords = ((size_t)n + 31) / 32, ncs = (size_t)ctx->grid_G * ctx->grid_G + 1;
+        size_t lds = ((nwords + 3) & ~(size_t)3) * 4 + NN_TAIL * 4;
+        A.lds_cstart = ncs * 4 <= 48 * 1024;
+        if (A.lds_cstart) lds += ((ncs + 3) & ~(size_t)3) * 4;
+        // a single tour (or a handful) is latency-bound: points and node ids in LDS; batches keep the LDS for occupancy
+        A.lds_pts = count <= ctx->cus && lds + (size_t)n * 20 + 64 <= ctx->lds_max;
+        if (A.lds_pts) lds += (size_t)n * 20;
+        const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+        const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>() : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>()
+                       : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>() : nn_grid_fn<TSPGPU_CEIL_2D>();
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        void *args[] = {&A};
+        HIP_TRY(hipLaunchKernel(fn, dim3(count), dim3(64), args, lds, ctx->stream));
+        launched = true;
+    }
+    if (!launched && ctx->d_mat && !ctx->otf) {
         // matrix mode: vector row reads, one or two 16-byte vectors per thread where n allows
         const int V = 16 / (int)elem_size(ctx->elem), nvec = ctx->ld / V;
         int BT = std::min(1024, std::max(64, (nvec + 63) & ~63));
@@ -3168,6 +3452,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_trace) hipFree(ctx->d_trace);
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->d_spts) hipFree(ctx->d_spts);
+    free_grid(ctx);
     if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); }
     for (auto e : ctx->ev) hipEventDestroy(e);
     hipStreamDestroy(ctx->stream);
@@ -3210,6 +3495,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
+    case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
     case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
@@ -3232,6 +3518,8 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 9: return ctx->plan_D;
     case 10: return ctx->otf ? 1 : 0;
     case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel)) ? 1 : 0;
+    case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
+    case 13: return ctx->grid_max_occ;
     }
     return -1;
 }
@@ -3258,7 +3546,7 @@ int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_
     }
     const double diag = std::sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
     ctx->cost_bound = (edge_weight_type == TSPGPU_ATT ? diag / std::sqrt(10.0) : diag) + 2.0;
-    return E_OK;
+    return build_grid(ctx, xy, n, x0, x1, y0, y1);
 }
 
 static int launch_build(tspgpu_ctx *ctx)

@@ -24,6 +24,7 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -145,7 +146,15 @@ int ensure_comm(tspgpu_multi *m)
     if (rc) return rc;
     const double t0 = now_s();
     m->comm.assign(m->G, nullptr);
-    M_NCCL(m->R.CommInitAll(m->comm.data(), m->G, m->dev.data()));
+    // RCCL prints a version banner on stdout when it initialises; the reference's stdout is a machine contract
+    // ("Cost: %.2f", scraped by scripts/compare_algs.py:72), so stdout points at stderr for the duration of the call
+    fflush(stdout);
+    const int saved = dup(STDOUT_FILENO);
+    if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+    const ncclResult_t ir = m->R.CommInitAll(m->comm.data(), m->G, m->dev.data());
+    fflush(stdout);
+    if (saved >= 0) { dup2(saved, STDOUT_FILENO); close(saved); }
+    if (ir != ncclSuccess) return mfail(m, E_INTERNAL, "ncclCommInitAll -> %s", m->R.GetErrorString(ir));
     m->rccl_init_s = now_s() - t0;
     m->comm_ready = true;
     return E_OK;

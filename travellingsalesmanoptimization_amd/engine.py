@@ -47,7 +47,8 @@ class Engine:
         self._ck(self.L.tspgpu_set_option(self.ctx, opt, int(value)))
 
     def info(self):
-        names = ["n", "ld", "elem", "kernel", "wgs_per_tour", "lds_bytes", "block", "symmetric", "cus", "depth", "matrix_free", "fused"]
+        names = ["n", "ld", "elem", "kernel", "wgs_per_tour", "lds_bytes", "block", "symmetric", "cus", "depth", "matrix_free", "fused",
+                 "nn_grid", "nn_grid_max_cell"]
         return {k: int(self.L.tspgpu_info(self.ctx, i)) for i, k in enumerate(names)}
 
     # ---- instance
