@@ -1743,56 +1743,80 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // per-thread state of the owned b's on the NEW state, from coalesced loads of the old one:
     // a node inside the reversed range swaps its left/right neighbour (and edge cost); the four
     // nodes around the range ends get one new neighbour.  No gather, no dependence on the move
-    // beyond scalars.  The workgroup that owns a slice of b's also writes their new records.
+    // beyond scalars.  Every thread needs only succ b and c[b][succ b] of its b's -- one range test
+    // and two selects per b (the successor is the RIGHT neighbour iff the direction is forward XOR
+    // the node sits inside the reversed range); the two nodes whose successor is new, and the lanes
+    // past the row, are patched in a branch almost no wave takes.  The full new record (position,
+    // both neighbours, both edge costs) is derived and stored only by the thread that owns the slice.
+    static_assert(HOIST, "the fused kernels are instantiated for NCH * V <= 16 only");
     BState<T, NCH> B;
     B.skm = 0;
-    unsigned qpk[PAY ? NCH : 1][PAY ? V / 2 : 1];      // new cell of every own b, 16-bit pairs (for the record)
     const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
+    const bool fwd = ndir > 0;
+    const int wrap_end = lo + M - n;                      // > 0 only when the reversed range wraps round the array end
+    const int spA = move ? (fwd ? x0 : x2) : -1, spA_s = fwd ? x2 : x0;    // successor spA_s over an edge of cost wA
+    const int spB = move ? (fwd ? x1 : x3) : -1, spB_s = fwd ? x3 : x1;    // successor spB_s over an edge of cost wB
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int ub0 = (c * BT + tid) * V;
         const bool mine = ub0 < n && ub0 / slice == (int)blockIdx.x;
-        constexpr int hc_dummy = 0;
-        const int hc = HOIST ? c : hc_dummy;
-        if constexpr (!HOIST) load_old(c, 0);
 #pragma unroll
         for (int v = 0; v < V; v++) {
-            const int b = (c * BT + tid) * V + v;
-            int q_o, l_o, r_o;
-            AT dl_v, dr_v;
+            int q_o, sb;
+            AT dn;
+            if constexpr (PAY) q_o = (int)q16[c][v]; else q_o = qv[c][v];
+            const bool inr = ((unsigned)(q_o - lo) < (unsigned)M) | (q_o < wrap_end);
+            const bool use_r = inr != fwd;
             if constexpr (PAY) {
-                q_o = (int)q16[hc][v];
-                l_o = (int)((unsigned)lv[hc][v] & 0xffffu); r_o = (int)((unsigned)lv[hc][v] >> 16);
-                dl_v = (AT)((unsigned)dlv[hc][v] & 0xffffu); dr_v = (AT)((unsigned)dlv[hc][v] >> 16);
-            } else { q_o = qv[hc][v]; l_o = lv[hc][v]; r_o = rv[hc][v]; dl_v = dlv[hc][v]; dr_v = drv[hc][v]; }
-            int r = q_o - lo;
-            if (r < 0) r += n;
-            const bool inr = r < M;
-            const int qn = inr ? wrap(lo + M - 1 - r, n) : q_o;
-            int l2 = inr ? r_o : l_o, r2 = inr ? l_o : r_o;
-            AT dl2 = inr ? dr_v : dl_v, dr2 = inr ? dl_v : dr_v;
-            if (move) {
-                if (b == x0) { r2 = x2; dr2 = wA; }
-                if (b == x3) { l2 = x1; dl2 = wB; }
-                if (b == x1) { r2 = x3; dr2 = wB; }
-                if (b == x2) { l2 = x0; dl2 = wA; }
+                const unsigned w = (unsigned)lv[c][v], d = (unsigned)dlv[c][v];
+                sb = (int)((use_r ? w >> 16 : w) & 0xffffu);
+                dn = (AT)((use_r ? d >> 16 : d) & 0xffffu);
+            } else { sb = use_r ? rv[c][v] : lv[c][v]; dn = use_r ? drv[c][v] : dlv[c][v]; }
+            bstate_set<T, NCH>(B, c, v, sb, dn, false, false);
+        }
+        if (((unsigned)(spA - ub0) < (unsigned)V) | ((unsigned)(spB - ub0) < (unsigned)V) | (ub0 + V > n)) {
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const int b = ub0 + v;
+                if (b == spA) bstate_set<T, NCH>(B, c, v, spA_s, wA, false, false);
+                if (b == spB) bstate_set<T, NCH>(B, c, v, spB_s, wB, false, false);
+                if (b >= n) bstate_set<T, NCH>(B, c, v, 0, (AT)0, true, false);
             }
-            if (mine && b < n) {
+        }
+        if (mine) {
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                const int b = ub0 + v;
+                int q_o, l_o, r_o;
+                AT dl_v, dr_v;
                 if constexpr (PAY) {
-                    (reinterpret_cast<u16 *>(A.F.pos[wr]) + tn)[b] = (u16)qn;
-                    (reinterpret_cast<unsigned *>(A.F.nl[wr]) + tn)[b] = (unsigned)l2 | ((unsigned)r2 << 16);
-                    (reinterpret_cast<unsigned *>(A.F.dl[wr]) + tn)[b] = (unsigned)dl2 | ((unsigned)dr2 << 16);
-                } else {
-                    A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
-                    reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
-                    reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
+                    q_o = (int)q16[c][v];
+                    l_o = (int)((unsigned)lv[c][v] & 0xffffu); r_o = (int)((unsigned)lv[c][v] >> 16);
+                    dl_v = (AT)((unsigned)dlv[c][v] & 0xffffu); dr_v = (AT)((unsigned)dlv[c][v] >> 16);
+                } else { q_o = qv[c][v]; l_o = lv[c][v]; r_o = rv[c][v]; dl_v = dlv[c][v]; dr_v = drv[c][v]; }
+                int r = q_o - lo;
+                if (r < 0) r += n;
+                const bool inr = r < M;
+                const int qn = inr ? wrap(lo + M - 1 - r, n) : q_o;
+                int l2 = inr ? r_o : l_o, r2 = inr ? l_o : r_o;
+                AT dl2 = inr ? dr_v : dl_v, dr2 = inr ? dl_v : dr_v;
+                if (move) {
+                    if (b == x0) { r2 = x2; dr2 = wA; }
+                    if (b == x3) { l2 = x1; dl2 = wB; }
+                    if (b == x1) { r2 = x3; dr2 = wB; }
+                    if (b == x2) { l2 = x0; dl2 = wA; }
                 }
-            }
-            const int sb = b < n ? (ndir > 0 ? r2 : l2) : 0;
-            const AT dn = ndir > 0 ? dr2 : dl2;
-            bstate_set<T, NCH>(B, c, v, sb, dn, b >= n, false);
-            if constexpr (PAY) {
-                if (v & 1) qpk[c][v / 2] |= (unsigned)qn << 16; else qpk[c][v / 2] = (unsigned)qn & 0xffffu;
+                if (b < n) {
+                    if constexpr (PAY) {
+                        (reinterpret_cast<u16 *>(A.F.pos[wr]) + tn)[b] = (u16)qn;
+                        (reinterpret_cast<unsigned *>(A.F.nl[wr]) + tn)[b] = (unsigned)l2 | ((unsigned)r2 << 16);
+                        (reinterpret_cast<unsigned *>(A.F.dl[wr]) + tn)[b] = (unsigned)dl2 | ((unsigned)dr2 << 16);
+                    } else {
+                        A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
+                        reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
+                        reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
+                    }
+                }
             }
         }
     }
@@ -1892,12 +1916,16 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
                 }
             }
             const int other = own == lb ? la : lb;
-            unsigned pk = 0, qq = 0;
+            unsigned pk = 0;
+            int q_old = 0;                        // old array cell of the own node; its new cell follows from the move
 #pragma unroll
             for (int c = 0; c < NCH; c++)
 #pragma unroll
                 for (int v = 0; v < V; v++)
-                    if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; qq = (v & 1) ? qpk[c][v / 2] >> 16 : qpk[c][v / 2] & 0xffffu; }
+                    if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; q_old = (int)q16[c][v]; }
+            int qr = q_old - lo;
+            if (qr < 0) qr += n;
+            const unsigned qq = (unsigned)(qr < M ? wrap(lo + M - 1 - qr, n) : q_old);
             const int sb = (int)(pk & 0xffffu) / (int)sizeof(T);
             int sidx = 0;
             for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
