@@ -652,9 +652,34 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     int step = 1;
     const int grid_steps = n - 1 > NN_TAIL ? n - 1 - NN_TAIL : 0;     // steps taken through the grid
 
+    // wave-wide minimum of a 64-bit key through DPP (no LDS crossbar: a ds_bpermute butterfly costs more than the
+    // whole candidate scan): quad swaps and the two mirrors leave every 16-lane row with its minimum, row_bcast15 /
+    // row_bcast31 carry it across the rows, lane 63 ends with the wave's
     auto wave_min = [&](u64 k) __attribute__((always_inline)) {
-        for (int off = 32; off > 0; off >>= 1) { const u64 o = __shfl_xor(k, off); k = o < k ? o : k; }
-        return k;
+        auto stepmin = [&](auto ctrl_tag, auto rows_tag) __attribute__((always_inline)) {
+            constexpr int CTRL = decltype(ctrl_tag)::value, ROWS = decltype(rows_tag)::value;
+            const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+            const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWS, 0xf, false);
+            const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWS, 0xf, false);
+            const u64 o = ((u64)ohi << 32) | olo;
+            k = o < k ? o : k;
+        };
+        typedef std::integral_constant<int, 0xf> ALL;
+        stepmin(std::integral_constant<int, 0xB1>{}, ALL{});      // quad_perm [1,0,3,2]
+        stepmin(std::integral_constant<int, 0x4E>{}, ALL{});      // quad_perm [2,3,0,1]
+        stepmin(std::integral_constant<int, 0x141>{}, ALL{});     // row_half_mirror
+        stepmin(std::integral_constant<int, 0x140>{}, ALL{});     // row_mirror
+        stepmin(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast15 -> rows 1, 3
+        stepmin(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast31 -> rows 2, 3
+        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+        return ((u64)rhi << 32) | rlo;
+    };
+    auto lane_f64 = [&](double x, int src) __attribute__((always_inline)) {      // x of lane `src` (wave-uniform) to all
+        const long long b = __double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, src);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((u64)b >> 32), src);
+        return __longlong_as_double((long long)(((u64)hi << 32) | lo));
     };
 
     for (; step <= grid_steps; step++) {
@@ -707,9 +732,9 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
             R += max(2, R >> 1);
         }
         // the lane that holds the winner (node ids are unique) hands over its position and coordinates
-        const int src = __ffsll((unsigned long long)__ballot(best == win)) - 1;
-        cur = __shfl(bestp, src);
-        P.x = __shfl(bestQ.x, src); P.y = __shfl(bestQ.y, src);
+        const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(best == win)) - 1);
+        cur = __builtin_amdgcn_readlane(bestp, src);
+        P.x = lane_f64(bestQ.x, src); P.y = lane_f64(bestQ.y, src);
         total += (double)(unsigned)(win >> 32);
         if (lane == 0) { ord[step] = (int)(win & 0xffffffffu); vis[cur >> 5] |= 1u << (cur & 31); }
         __syncthreads();
@@ -760,8 +785,8 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (((alive >> u) & 1u) && qid[u] == nxt) { alive &= ~(1u << u); px = Q[u].x; py = Q[u].y; }
-            const int src = __ffsll((unsigned long long)__ballot(best == win)) - 1;
-            P.x = __shfl(px, src); P.y = __shfl(py, src);
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(best == win)) - 1);
+            P.x = lane_f64(px, src); P.y = lane_f64(py, src);
             if (lane == 0) ord[step] = nxt;
         }
         if (lane == 0) {
