@@ -682,54 +682,90 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
         return __longlong_as_double((long long)(((u64)hi << 32) | lo));
     };
 
+    // a single wave: LDS operations of one wave complete in order, so lane 0's update of the visited bits needs no
+    // workgroup barrier before the next step reads them -- only the compiler must not move LDS accesses across it
+    // (__syncthreads() would also wait for the global store of ord[step], a full memory round trip per step)
+#define NN_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    const unsigned wlb2 = (unsigned)edge_w<KIND>(0.0, 0.0, fmax(0.0, 2.0 * A.cell - A.eps), 0.0);   // weight bound of the first square
+    const int jl5 = lane / 12, k5 = lane - jl5 * 12;          // first square: 5 grid rows x 12 lanes
+
     for (; step <= grid_steps; step++) {
         const int cx = min(G - 1, max(0, (int)((P.x - A.x0) * A.inv_cell)));
         const int cy = min(G - 1, max(0, (int)((P.y - A.y0) * A.inv_cell)));
         u64 best = KEY_NONE;                        // lane's best candidate: weight << 32 | node ...
         int bestp = 0;                              // ... its sorted position and coordinates
         double2 bestQ = make_double2(0, 0);
+        // candidate at sorted position p (loads first, branch-free: a visited point just loses)
         auto cand = [&](int p) __attribute__((always_inline)) {
-            if ((vis[p >> 5] >> (p & 31)) & 1u) return;
+            const unsigned vw = vis[p >> 5];
             const double2 Q = pts[p];
-            const u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q.x, Q.y) << 32) | (unsigned)gidx[p];
+            const unsigned id = (unsigned)gidx[p];
+            u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q.x, Q.y) << 32) | id;
+            key = ((vw >> (p & 31)) & 1u) ? KEY_NONE : key;
             if (key < best) { best = key; bestp = p; bestQ = Q; }
         };
-        int Rin = -1, R = 2;                        // cells within Rin of (cx, cy) are done
-        u64 win;
-        for (;;) {
-            const int ylo = max(0, cy - R), yhi = min(G - 1, cy + R);
-            const int xlo = max(0, cx - R), xhi = min(G - 1, cx + R);
-            const int nrows = yhi - ylo + 1;
-            const int L = nrows >= 64 ? 1 : 64 / nrows;           // lanes per grid row
-            const int rpp = 64 / L;                               // grid rows per pass
-            for (int r0 = 0; r0 < nrows; r0 += rpp) {
-                const int jl = lane / L, k = lane - jl * L, j = r0 + jl;
-                if (jl < rpp && j < nrows) {
-                    const int y = ylo + j;
-                    const int rowbase = y * G;
-                    // new cells of this row: the whole span outside the inner square's rows, its two flanks inside
-                    const bool inner = Rin >= 0 && y >= cy - Rin && y <= cy + Rin;
-                    const int s1 = cstart[rowbase + xlo];
-                    int e1, s2 = 0, e2 = 0;
-                    if (!inner) e1 = cstart[rowbase + xhi + 1];
-                    else {
-                        const int ixlo = max(0, cx - Rin), ixhi = min(G - 1, cx + Rin);
-                        e1 = cstart[rowbase + ixlo];
-                        s2 = cstart[rowbase + ixhi + 1]; e2 = cstart[rowbase + xhi + 1];
-                    }
-                    for (int p = s1 + k; p < e1; p += L) cand(p);
-                    for (int p = s2 + k; p < e2; p += L) cand(p);
-                }
+        auto cand2 = [&](int p, int q) __attribute__((always_inline)) {   // two candidates, their chains interleaved
+            const unsigned vw0 = vis[p >> 5], vw1 = vis[q >> 5];
+            const double2 Q0 = pts[p], Q1 = pts[q];
+            const unsigned id0 = (unsigned)gidx[p], id1 = (unsigned)gidx[q];
+            u64 k0 = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q0.x, Q0.y) << 32) | id0;
+            u64 k1 = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q1.x, Q1.y) << 32) | id1;
+            k0 = ((vw0 >> (p & 31)) & 1u) ? KEY_NONE : k0;
+            k1 = ((vw1 >> (q & 31)) & 1u) ? KEY_NONE : k1;
+            const bool second = k1 < k0;
+            const u64 km = second ? k1 : k0;
+            if (km < best) { best = km; bestp = second ? q : p; bestQ.x = second ? Q1.x : Q0.x; bestQ.y = second ? Q1.y : Q0.y; }
+        };
+        // first square, R = 2 (almost always the only one): one contiguous range of sorted positions per grid row
+        {
+            const int y = cy - 2 + jl5;
+            if (jl5 < 5 && y >= 0 && y < G) {
+                const int rowbase = y * G;
+                const int s1 = cstart[rowbase + max(0, cx - 2)], e1 = cstart[rowbase + min(G - 1, cx + 2) + 1];
+                int p = s1 + k5;
+                for (; p + 12 < e1; p += 24) cand2(p, p + 12);
+                if (p < e1) cand(p);
             }
-            win = wave_min(best);
-            const bool whole = xlo == 0 && ylo == 0 && xhi == G - 1 && yhi == G - 1;
-            if (win != KEY_NONE) {
-                // every point not examined yet is at least R cells away from the current node
-                const double lb = fmax(0.0, (double)R * A.cell - A.eps);
-                if (whole || (u64)(unsigned)edge_w<KIND>(0.0, 0.0, lb, 0.0) > (win >> 32)) break;
-            } else if (whole) break;                              // (cannot happen: unvisited nodes remain)
-            Rin = R;
-            R += max(2, R >> 1);
+        }
+        u64 win = wave_min(best);
+        const bool whole2 = cx - 2 <= 0 && cy - 2 <= 0 && cx + 2 >= G - 1 && cy + 2 >= G - 1;
+        if (!(win != KEY_NONE && (whole2 || wlb2 > (unsigned)(win >> 32))) && !whole2) {
+            int Rin = 2, R = 4;                     // cells within Rin of (cx, cy) are done
+            for (;;) {
+                const int ylo = max(0, cy - R), yhi = min(G - 1, cy + R);
+                const int xlo = max(0, cx - R), xhi = min(G - 1, cx + R);
+                const int nrows = yhi - ylo + 1;
+                const int L = nrows >= 64 ? 1 : 64 / nrows;           // lanes per grid row
+                const int rpp = 64 / L;                               // grid rows per pass
+                for (int r0 = 0; r0 < nrows; r0 += rpp) {
+                    const int jl = lane / L, k = lane - jl * L, j = r0 + jl;
+                    if (jl < rpp && j < nrows) {
+                        const int y = ylo + j;
+                        const int rowbase = y * G;
+                        // new cells of this row: the whole span outside the inner square's rows, its two flanks inside
+                        const bool inner = y >= cy - Rin && y <= cy + Rin;
+                        const int s1 = cstart[rowbase + xlo];
+                        int e1, s2 = 0, e2 = 0;
+                        if (!inner) e1 = cstart[rowbase + xhi + 1];
+                        else {
+                            const int ixlo = max(0, cx - Rin), ixhi = min(G - 1, cx + Rin);
+                            e1 = cstart[rowbase + ixlo];
+                            s2 = cstart[rowbase + ixhi + 1]; e2 = cstart[rowbase + xhi + 1];
+                        }
+                        for (int p = s1 + k; p < e1; p += L) cand(p);
+                        for (int p = s2 + k; p < e2; p += L) cand(p);
+                    }
+                }
+                win = wave_min(best);
+                const bool whole = xlo == 0 && ylo == 0 && xhi == G - 1 && yhi == G - 1;
+                if (win != KEY_NONE) {
+                    // every point not examined yet is at least R cells away from the current node
+                    const double lb = fmax(0.0, (double)R * A.cell - A.eps);
+                    if (whole || (u64)(unsigned)edge_w<KIND>(0.0, 0.0, lb, 0.0) > (win >> 32)) break;
+                } else if (whole) break;                              // (cannot happen: unvisited nodes remain)
+                Rin = R;
+                R += max(2, R >> 1);
+            }
         }
         // the lane that holds the winner (node ids are unique) hands over its position and coordinates
         const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(best == win)) - 1);
@@ -737,8 +773,9 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
         P.x = lane_f64(bestQ.x, src); P.y = lane_f64(bestQ.y, src);
         total += (double)(unsigned)(win >> 32);
         if (lane == 0) { ord[step] = (int)(win & 0xffffffffu); vis[cur >> 5] |= 1u << (cur & 31); }
-        __syncthreads();
+        NN_WAVE_SYNC();
     }
+#undef NN_WAVE_SYNC
 
     // ---- the last <= NN_TAIL unvisited nodes: in registers, four per lane
     {
