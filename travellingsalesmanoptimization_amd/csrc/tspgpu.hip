@@ -609,42 +609,50 @@ struct GridArgs {
     const int *starts;
     const double2 *gxy;      // [n] points, sorted by cell
     const int *gidx;         // [n] sorted position -> node
+    const int *gcell;        // [n] sorted position -> cell (cx | cy << 16)
     const int *gpos;         // [n] node -> sorted position
     const int *cstart;       // [G*G + 1] first sorted position of every cell
     int G;
-    double x0, y0, cell, inv_cell, eps;
-    int lds_pts;             // points + node ids copied into LDS (single tours; batches read them through L2)
-    int lds_cstart;          // cell starts copied into LDS
+    double cell, eps;
 };
 
 constexpr int NN_TAIL = 256;
 
-template <int KIND>
+// LDS_PTS / LDS_CS: points + node ids + cells / cell starts staged in LDS -- compile-time, so that every access is a
+// ds_read with a 32-bit address (a run-time choice of pointer turns them all into flat loads).  KEY32: weights below
+// 2^15 and n <= 2^17, the candidate key (weight, node) is ONE 32-bit word and a reduction step one v_min_u32.
+template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32>
 __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
 {
+    typedef typename std::conditional<KEY32, unsigned, u64>::type K;
+    constexpr K NONE = (K)~(K)0;
+    constexpr int WSH = KEY32 ? 17 : 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n = A.n, G = A.G, lane = threadIdx.x;
     const int t = A.slot0 + blockIdx.x;
     const int start = A.starts[blockIdx.x];
     int *ord = A.S.ord + (size_t)t * n;
-    // LDS: visited bits | tail list | (cell starts) | (points, node ids)
+    // LDS: visited bits | tail list | (cell starts) | (points, node ids, cells)
     const int nwords = (n + 31) >> 5;
     unsigned *vis = reinterpret_cast<unsigned *>(smem);
     int *tail = reinterpret_cast<int *>(vis + ((nwords + 3) & ~3));
     int *cs_l = tail + NN_TAIL;
     const int ncs = G * G + 1;
-    double2 *pts_l = reinterpret_cast<double2 *>(cs_l + (A.lds_cstart ? ((ncs + 3) & ~3) : 0));
-    int *idx_l = reinterpret_cast<int *>(pts_l + (A.lds_pts ? n : 0));
+    double2 *pts_l = reinterpret_cast<double2 *>(cs_l + (LDS_CS ? ((ncs + 3) & ~3) : 0));
+    int *idx_l = reinterpret_cast<int *>(pts_l + (LDS_PTS ? n : 0));
+    int *cell_l = idx_l + (LDS_PTS ? n : 0);
     for (int w = lane; w < nwords; w += 64) vis[w] = 0;
-    if (A.lds_cstart) for (int i = lane; i < ncs; i += 64) cs_l[i] = A.cstart[i];
-    if (A.lds_pts) for (int i = lane; i < n; i += 64) { pts_l[i] = A.gxy[i]; idx_l[i] = A.gidx[i]; }
+    if constexpr (LDS_CS) for (int i = lane; i < ncs; i += 64) cs_l[i] = A.cstart[i];
+    if constexpr (LDS_PTS) for (int i = lane; i < n; i += 64) { pts_l[i] = A.gxy[i]; idx_l[i] = A.gidx[i]; cell_l[i] = A.gcell[i]; }
     __syncthreads();
-    const int *cstart = A.lds_cstart ? cs_l : A.cstart;
-    const double2 *pts = A.lds_pts ? pts_l : A.gxy;
-    const int *gidx = A.lds_pts ? idx_l : A.gidx;
+    auto cstart = [&](int i) __attribute__((always_inline)) { if constexpr (LDS_CS) return cs_l[i]; else return A.cstart[i]; };
+    auto pts = [&](int i) __attribute__((always_inline)) { if constexpr (LDS_PTS) return pts_l[i]; else return A.gxy[i]; };
+    auto gidx = [&](int i) __attribute__((always_inline)) { if constexpr (LDS_PTS) return idx_l[i]; else return A.gidx[i]; };
+    auto gcell = [&](int i) __attribute__((always_inline)) { if constexpr (LDS_PTS) return cell_l[i]; else return A.gcell[i]; };
 
     int cur = A.gpos[start];                       // sorted position of the current node (wave-uniform)
     double2 P = A.gxy[cur];                        // its coordinates (wave-uniform)
+    int ccell = A.gcell[cur];                      // its cell
     const double2 P0 = P;
     if (lane == 0) { ord[0] = start; vis[cur >> 5] |= 1u << (cur & 31); }
     __syncthreads();
@@ -652,17 +660,22 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     int step = 1;
     const int grid_steps = n - 1 > NN_TAIL ? n - 1 - NN_TAIL : 0;     // steps taken through the grid
 
-    // wave-wide minimum of a 64-bit key through DPP (no LDS crossbar: a ds_bpermute butterfly costs more than the
-    // whole candidate scan): quad swaps and the two mirrors leave every 16-lane row with its minimum, row_bcast15 /
+    // wave-wide minimum of a key through DPP (no LDS crossbar: a ds_bpermute butterfly costs more than the whole
+    // candidate scan): quad swaps and the two mirrors leave every 16-lane row with its minimum, row_bcast15 /
     // row_bcast31 carry it across the rows, lane 63 ends with the wave's
-    auto wave_min = [&](u64 k) __attribute__((always_inline)) {
+    auto wave_min = [&](K k) __attribute__((always_inline)) {
         auto stepmin = [&](auto ctrl_tag, auto rows_tag) __attribute__((always_inline)) {
             constexpr int CTRL = decltype(ctrl_tag)::value, ROWS = decltype(rows_tag)::value;
-            const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
-            const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWS, 0xf, false);
-            const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWS, 0xf, false);
-            const u64 o = ((u64)ohi << 32) | olo;
-            k = o < k ? o : k;
+            if constexpr (KEY32) {
+                const unsigned o = (unsigned)__builtin_amdgcn_update_dpp((int)k, (int)k, CTRL, ROWS, 0xf, false);
+                k = o < k ? o : k;
+            } else {
+                const unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);
+                const unsigned olo = (unsigned)__builtin_amdgcn_update_dpp((int)lo, (int)lo, CTRL, ROWS, 0xf, false);
+                const unsigned ohi = (unsigned)__builtin_amdgcn_update_dpp((int)hi, (int)hi, CTRL, ROWS, 0xf, false);
+                const u64 o = ((u64)ohi << 32) | olo;
+                k = o < k ? o : k;
+            }
         };
         typedef std::integral_constant<int, 0xf> ALL;
         stepmin(std::integral_constant<int, 0xB1>{}, ALL{});      // quad_perm [1,0,3,2]
@@ -671,9 +684,12 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
         stepmin(std::integral_constant<int, 0x140>{}, ALL{});     // row_mirror
         stepmin(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xA>{});   // row_bcast15 -> rows 1, 3
         stepmin(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xC>{});   // row_bcast31 -> rows 2, 3
-        const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
-        const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
-        return ((u64)rhi << 32) | rlo;
+        if constexpr (KEY32) return (K)(unsigned)__builtin_amdgcn_readlane((int)k, 63);
+        else {
+            const unsigned rlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)k, 63);
+            const unsigned rhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+            return (K)(((u64)rhi << 32) | rlo);
+        }
     };
     auto lane_f64 = [&](double x, int src) __attribute__((always_inline)) {      // x of lane `src` (wave-uniform) to all
         const long long b = __double_as_longlong(x);
@@ -681,6 +697,9 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)((u64)b >> 32), src);
         return __longlong_as_double((long long)(((u64)hi << 32) | lo));
     };
+    auto make_key = [&](int w, unsigned id) __attribute__((always_inline)) { return (K)(((K)(unsigned)w << WSH) | (K)id); };
+    auto key_w = [&](K k) __attribute__((always_inline)) { return (unsigned)(k >> WSH); };
+    auto key_id = [&](K k) __attribute__((always_inline)) { return (int)(KEY32 ? (unsigned)k & 0x1ffffu : (unsigned)k); };
 
     // a single wave: LDS operations of one wave complete in order, so lane 0's update of the visited bits needs no
     // workgroup barrier before the next step reads them -- only the compiler must not move LDS accesses across it
@@ -690,46 +709,34 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     const int jl5 = lane / 12, k5 = lane - jl5 * 12;          // first square: 5 grid rows x 12 lanes
 
     for (; step <= grid_steps; step++) {
-        const int cx = min(G - 1, max(0, (int)((P.x - A.x0) * A.inv_cell)));
-        const int cy = min(G - 1, max(0, (int)((P.y - A.y0) * A.inv_cell)));
-        u64 best = KEY_NONE;                        // lane's best candidate: weight << 32 | node ...
-        int bestp = 0;                              // ... its sorted position and coordinates
-        double2 bestQ = make_double2(0, 0);
-        // candidate at sorted position p (loads first, branch-free: a visited point just loses)
-        auto cand = [&](int p) __attribute__((always_inline)) {
+        const int cx = ccell & 0xffff, cy = ccell >> 16;
+        K best = NONE;                              // lane's best candidate: (weight, node) ...
+        int bestp = 0;                              // ... and its sorted position
+        // candidate at sorted position p, taken when `ok` (loads first, branch-free: a visited point just loses)
+        auto cand = [&](int p, bool ok) __attribute__((always_inline)) {
             const unsigned vw = vis[p >> 5];
-            const double2 Q = pts[p];
-            const unsigned id = (unsigned)gidx[p];
-            u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q.x, Q.y) << 32) | id;
-            key = ((vw >> (p & 31)) & 1u) ? KEY_NONE : key;
-            if (key < best) { best = key; bestp = p; bestQ = Q; }
+            const double2 Q = pts(p);
+            const unsigned id = (unsigned)gidx(p);
+            K key = make_key(edge_w<KIND>(P.x, P.y, Q.x, Q.y), id);
+            key = (!ok || ((vw >> (p & 31)) & 1u)) ? NONE : key;
+            if (key < best) { best = key; bestp = p; }
         };
-        auto cand2 = [&](int p, int q) __attribute__((always_inline)) {   // two candidates, their chains interleaved
-            const unsigned vw0 = vis[p >> 5], vw1 = vis[q >> 5];
-            const double2 Q0 = pts[p], Q1 = pts[q];
-            const unsigned id0 = (unsigned)gidx[p], id1 = (unsigned)gidx[q];
-            u64 k0 = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q0.x, Q0.y) << 32) | id0;
-            u64 k1 = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q1.x, Q1.y) << 32) | id1;
-            k0 = ((vw0 >> (p & 31)) & 1u) ? KEY_NONE : k0;
-            k1 = ((vw1 >> (q & 31)) & 1u) ? KEY_NONE : k1;
-            const bool second = k1 < k0;
-            const u64 km = second ? k1 : k0;
-            if (km < best) { best = km; bestp = second ? q : p; bestQ.x = second ? Q1.x : Q0.x; bestQ.y = second ? Q1.y : Q0.y; }
-        };
-        // first square, R = 2 (almost always the only one): one contiguous range of sorted positions per grid row
+        // first square, R = 2 (almost always the only one): one contiguous range of sorted positions per grid row,
+        // two candidates per lane in straight-line code (their chains interleave), the rest of a long range in a loop
         {
             const int y = cy - 2 + jl5;
-            if (jl5 < 5 && y >= 0 && y < G) {
-                const int rowbase = y * G;
-                const int s1 = cstart[rowbase + max(0, cx - 2)], e1 = cstart[rowbase + min(G - 1, cx + 2) + 1];
-                int p = s1 + k5;
-                for (; p + 12 < e1; p += 24) cand2(p, p + 12);
-                if (p < e1) cand(p);
-            }
+            const bool row = jl5 < 5 && y >= 0 && y < G;
+            const int rowbase = row ? y * G : 0;
+            const int s1 = cstart(rowbase + max(0, cx - 2)), e1 = row ? cstart(rowbase + min(G - 1, cx + 2) + 1) : 0;
+            const int p0 = s1 + k5, p1 = p0 + 12;
+            cand(min(p0, n - 1), p0 < e1);
+            cand(min(p1, n - 1), p1 < e1);
+            if (__ballot(p1 + 12 < e1))
+                for (int p = p1 + 12; p < e1; p += 12) cand(p, true);
         }
-        u64 win = wave_min(best);
+        K win = wave_min(best);
         const bool whole2 = cx - 2 <= 0 && cy - 2 <= 0 && cx + 2 >= G - 1 && cy + 2 >= G - 1;
-        if (!(win != KEY_NONE && (whole2 || wlb2 > (unsigned)(win >> 32))) && !whole2) {
+        if (!whole2 && (win == NONE || wlb2 <= key_w(win))) {
             int Rin = 2, R = 4;                     // cells within Rin of (cx, cy) are done
             for (;;) {
                 const int ylo = max(0, cy - R), yhi = min(G - 1, cy + R);
@@ -744,35 +751,41 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
                         const int rowbase = y * G;
                         // new cells of this row: the whole span outside the inner square's rows, its two flanks inside
                         const bool inner = y >= cy - Rin && y <= cy + Rin;
-                        const int s1 = cstart[rowbase + xlo];
+                        const int s1 = cstart(rowbase + xlo);
                         int e1, s2 = 0, e2 = 0;
-                        if (!inner) e1 = cstart[rowbase + xhi + 1];
+                        if (!inner) e1 = cstart(rowbase + xhi + 1);
                         else {
                             const int ixlo = max(0, cx - Rin), ixhi = min(G - 1, cx + Rin);
-                            e1 = cstart[rowbase + ixlo];
-                            s2 = cstart[rowbase + ixhi + 1]; e2 = cstart[rowbase + xhi + 1];
+                            e1 = cstart(rowbase + ixlo);
+                            s2 = cstart(rowbase + ixhi + 1); e2 = cstart(rowbase + xhi + 1);
                         }
-                        for (int p = s1 + k; p < e1; p += L) cand(p);
-                        for (int p = s2 + k; p < e2; p += L) cand(p);
+                        for (int p = s1 + k; p < e1; p += L) cand(p, true);
+                        for (int p = s2 + k; p < e2; p += L) cand(p, true);
                     }
                 }
                 win = wave_min(best);
                 const bool whole = xlo == 0 && ylo == 0 && xhi == G - 1 && yhi == G - 1;
-                if (win != KEY_NONE) {
+                if (win != NONE) {
                     // every point not examined yet is at least R cells away from the current node
                     const double lb = fmax(0.0, (double)R * A.cell - A.eps);
-                    if (whole || (u64)(unsigned)edge_w<KIND>(0.0, 0.0, lb, 0.0) > (win >> 32)) break;
+                    if (whole || (unsigned)edge_w<KIND>(0.0, 0.0, lb, 0.0) > key_w(win)) break;
                 } else if (whole) break;                              // (cannot happen: unvisited nodes remain)
                 Rin = R;
                 R += max(2, R >> 1);
             }
         }
-        // the lane that holds the winner (node ids are unique) hands over its position and coordinates
+        // the lane that holds the winner (node ids are unique) hands over its sorted position; coordinates and cell of
+        // the new current node come from there (LDS: a uniform read; global arrays: the winner's lane loads them)
         const int src = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)__ballot(best == win)) - 1);
         cur = __builtin_amdgcn_readlane(bestp, src);
-        P.x = lane_f64(bestQ.x, src); P.y = lane_f64(bestQ.y, src);
-        total += (double)(unsigned)(win >> 32);
-        if (lane == 0) { ord[step] = (int)(win & 0xffffffffu); vis[cur >> 5] |= 1u << (cur & 31); }
+        if constexpr (LDS_PTS) { P = pts(cur); ccell = __builtin_amdgcn_readfirstlane(gcell(cur)); }
+        else {
+            const double2 Q = A.gxy[bestp];                           // (every lane loads its own best: in flight together)
+            const int qc = A.gcell[bestp];
+            P.x = lane_f64(Q.x, src); P.y = lane_f64(Q.y, src); ccell = __builtin_amdgcn_readlane(qc, src);
+        }
+        total += (double)key_w(win);
+        if (lane == 0) { ord[step] = key_id(win); vis[cur >> 5] |= 1u << (cur & 31); }
         NN_WAVE_SYNC();
     }
 #undef NN_WAVE_SYNC
@@ -809,15 +822,15 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
             if (e < remaining) { const int p = tail[e]; Q[u] = A.gxy[p]; qid[u] = A.gidx[p]; alive |= 1u << u; }
         }
         for (; step < n; step++) {
-            u64 best = KEY_NONE;
+            K best = NONE;
 #pragma unroll
             for (int u = 0; u < U; u++) {
-                const u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q[u].x, Q[u].y) << 32) | (unsigned)qid[u];
+                const K key = make_key(edge_w<KIND>(P.x, P.y, Q[u].x, Q[u].y), (unsigned)qid[u]);
                 best = (((alive >> u) & 1u) && key < best) ? key : best;
             }
-            const u64 win = wave_min(best);
-            const int nxt = (int)(win & 0xffffffffu);
-            total += (double)(unsigned)(win >> 32);
+            const K win = wave_min(best);
+            const int nxt = key_id(win);
+            total += (double)key_w(win);
             double px = 0, py = 0;
 #pragma unroll
             for (int u = 0; u < U; u++)
@@ -2499,7 +2512,7 @@ struct tspgpu_ctx {
     int opt_otf = 0;         // 0 auto, 1 force matrix-free, 2 never
     double2 *d_spts = nullptr; size_t spts_cap = 0;
     // uniform grid over the points for the grid NN (k_nn_grid): built on the host in tspgpu_set_points
-    double2 *d_gxy = nullptr; int *d_gidx = nullptr, *d_gpos = nullptr, *d_cstart = nullptr;
+    double2 *d_gxy = nullptr; int *d_gidx = nullptr, *d_gpos = nullptr, *d_cstart = nullptr, *d_gcell = nullptr;
     int grid_G = 0, grid_max_occ = 0; bool grid_ok = false;
     double grid_x0 = 0, grid_y0 = 0, grid_cell = 1, grid_inv = 0, grid_eps = 0;
     int opt_nn = 0;          // 0 auto, 1 matrix / strided kernels, 2 grid kernel
@@ -2603,9 +2616,9 @@ static void free_tour_scratch(tspgpu_ctx *ctx)
 
 static void free_grid(tspgpu_ctx *ctx)
 {
-    void *ptrs[] = {ctx->d_gxy, ctx->d_gidx, ctx->d_gpos, ctx->d_cstart};
+    void *ptrs[] = {ctx->d_gxy, ctx->d_gidx, ctx->d_gpos, ctx->d_cstart, ctx->d_gcell};
     for (void *p : ptrs) if (p) hipFree(p);
-    ctx->d_gxy = nullptr; ctx->d_gidx = ctx->d_gpos = ctx->d_cstart = nullptr;
+    ctx->d_gxy = nullptr; ctx->d_gidx = ctx->d_gpos = ctx->d_cstart = ctx->d_gcell = nullptr;
     ctx->grid_G = 0; ctx->grid_ok = false;
 }
 
@@ -3409,11 +3422,18 @@ static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, doubl
     std::vector<int> fill(cstart.begin(), cstart.end() - 1);
     for (int i = 0; i < n; i++) { const int p = fill[cid[i]]++; gidx[p] = i; gpos[i] = p; }   // node order inside a cell
     std::vector<double> gxy((size_t)2 * n);
-    for (int p = 0; p < n; p++) { gxy[2 * p] = xy[2 * gidx[p]]; gxy[2 * p + 1] = xy[2 * gidx[p] + 1]; }
+    std::vector<int> gcell(n);
+    for (int p = 0; p < n; p++) {
+        gxy[2 * p] = xy[2 * gidx[p]]; gxy[2 * p + 1] = xy[2 * gidx[p] + 1];
+        const int c = cid[gidx[p]];
+        gcell[p] = (c % G) | ((c / G) << 16);
+    }
     HIP_TRY(hipMalloc(&ctx->d_gxy, (size_t)n * sizeof(double2)));
     HIP_TRY(hipMalloc(&ctx->d_gidx, (size_t)n * 4));
     HIP_TRY(hipMalloc(&ctx->d_gpos, (size_t)n * 4));
     HIP_TRY(hipMalloc(&ctx->d_cstart, (C + 1) * 4));
+    HIP_TRY(hipMalloc(&ctx->d_gcell, (size_t)n * 4));
+    HIP_TRY(hipMemcpy(ctx->d_gcell, gcell.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_gxy, gxy.data(), (size_t)n * sizeof(double2), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_gidx, gidx.data(), (size_t)n * 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->d_gpos, gpos.data(), (size_t)n * 4, hipMemcpyHostToDevice));
@@ -3424,7 +3444,12 @@ static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, doubl
     return E_OK;
 }
 
-template <int KIND> static const void *nn_grid_fn() { return (const void *)k_nn_grid<KIND>; }
+template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32)
+{
+    if (lds_pts && lds_cs) return key32 ? (const void *)k_nn_grid<KIND, true, true, true> : (const void *)k_nn_grid<KIND, true, true, false>;
+    if (lds_pts) return (const void *)k_nn_grid<KIND, true, false, false>;
+    return lds_cs ? (const void *)k_nn_grid<KIND, false, true, false> : (const void *)k_nn_grid<KIND, false, false, false>;
+}
 
 // NN tours from h_starts into ord[] / cost[] of slots [slot0, slot0+count).  The slots are NOT complete tour states
 // afterwards (init_slots derives pos / succ / edge costs); they are marked invalid here and valid again by the callers
@@ -3443,19 +3468,19 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
     if (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) {
         GridArgs A;
         A.S = ctx->S; A.n = n; A.slot0 = slot0; A.starts = ctx->d_starts;
-        A.gxy = ctx->d_gxy; A.gidx = ctx->d_gidx; A.gpos = ctx->d_gpos; A.cstart = ctx->d_cstart;
-        A.G = ctx->grid_G; A.x0 = ctx->grid_x0; A.y0 = ctx->grid_y0; A.cell = ctx->grid_cell; A.inv_cell = ctx->grid_inv;
-        A.eps = ctx->grid_eps;
+        A.gxy = ctx->d_gxy; A.gidx = ctx->d_gidx; A.gcell = ctx->d_gcell; A.gpos = ctx->d_gpos; A.cstart = ctx->d_cstart;
+        A.G = ctx->grid_G; A.cell = ctx->grid_cell; A.eps = ctx->grid_eps;
         const size_t nwords = ((size_t)n + 31) / 32, ncs = (size_t)ctx->grid_G * ctx->grid_G + 1;
         size_t lds = ((nwords + 3) & ~(size_t)3) * 4 + NN_TAIL * 4;
-        A.lds_cstart = ncs * 4 <= 48 * 1024;
-        if (A.lds_cstart) lds += ((ncs + 3) & ~(size_t)3) * 4;
-        // a single tour (or a handful) is latency-bound: points and node ids in LDS; batches keep the LDS for occupancy
-        A.lds_pts = count <= ctx->cus && lds + (size_t)n * 20 + 64 <= ctx->lds_max;
-        if (A.lds_pts) lds += (size_t)n * 20;
+        const bool lc = ncs * 4 <= 48 * 1024;
+        if (lc) lds += ((ncs + 3) & ~(size_t)3) * 4;
+        // a single tour (or a handful) is latency-bound: points, node ids and cells in LDS; batches keep the LDS for occupancy
+        const bool lp = count <= ctx->cus && lds + (size_t)n * 24 + 64 <= ctx->lds_max;
+        if (lp) lds += (size_t)n * 24;
+        const bool key32 = ctx->cost_bound < 32767.0 && n <= 131072;      // (weight << 17 | node) in one 32-bit word, below the "none" key
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
-        const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>() : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>()
-                       : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>() : nn_grid_fn<TSPGPU_CEIL_2D>();
+        const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>(lp, lc, key32) : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>(lp, lc, key32)
+                       : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>(lp, lc, key32) : nn_grid_fn<TSPGPU_CEIL_2D>(lp, lc, key32);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void *args[] = {&A};
         HIP_TRY(hipLaunchKernel(fn, dim3(count), dim3(64), args, lds, ctx->stream));
