@@ -55,3 +55,29 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower(), (dirpath, f)
+
+
+def test_tsplib_reader_follows_the_reference_rules(tmp_path):
+    """travellingsalesmanoptimization_amd/tsplib.py (the harness's reader: tools/, examples): the acceptance rules of
+    src/tsp.c:527-606 -- EUC_2D only unless extensions are allowed, TYPE : TSP, one DIMENSION -- and the same points
+    as the oracle's reader on the committed instances"""
+    import numpy as np
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    from travellingsalesmanoptimization_amd import tsplib, _lib
+    data = os.path.join(ROOT, "tests", "golden", "data")
+    for name, kind in (("berlin52", _lib.EUC_2D), ("att48", _lib.ATT), ("pr1002", _lib.EUC_2D)):
+        xy, k = tsplib.read(os.path.join(data, name + ".tsp"))
+        want, _ = O.read_tsplib(os.path.join(data, name + ".tsp"))
+        assert k == kind and np.array_equal(xy, want)
+    with pytest.raises(ValueError):
+        tsplib.read(os.path.join(data, "att48.tsp"), allow_extensions=False)     # src/tsp.c:576-584
+    bad = tmp_path / "two_dims.tsp"
+    bad.write_text("TYPE : TSP\nDIMENSION : 4\nDIMENSION : 4\nEDGE_WEIGHT_TYPE : EUC_2D\nNODE_COORD_SECTION\n1 0 0\nEOF\n")
+    with pytest.raises(ValueError):
+        tsplib.read(str(bad))
+    atsp = tmp_path / "atsp.tsp"
+    atsp.write_text("TYPE : ATSP\nDIMENSION : 4\n")
+    with pytest.raises(ValueError):
+        tsplib.read(str(atsp))
