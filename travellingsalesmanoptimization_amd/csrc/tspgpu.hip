@@ -143,15 +143,55 @@ __device__ __forceinline__ bool key_better(double d1, u64 k1, double d2, u64 k2)
     return d1 < d2 || (d1 == d2 && k1 < k2);
 }
 
+// Wave-wide reductions through DPP (data-parallel primitives: the operand of a VALU instruction comes from another
+// lane of the same 16-lane row, or, row_bcast15 / row_bcast31, from the last lane of the rows before) instead of
+// __shfl_xor, which hipcc lowers to ds_bpermute: six dependent trips through the LDS crossbar per butterfly, at the end
+// of EVERY sweep workgroup and in every nearest-neighbour step.  Quad swaps and the two mirrors leave each row with
+// its minimum, the two broadcasts carry it across the rows; lane 63 ends with the wave's, v_readlane hands it out.
+template <int CTRL, int ROWS> __device__ __forceinline__ unsigned dpp_u32(unsigned x)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, CTRL, ROWS, 0xf, false);
+}
+template <int CTRL, int ROWS> __device__ __forceinline__ u64 dpp_u64(u64 x)
+{
+    return ((u64)dpp_u32<CTRL, ROWS>((unsigned)(x >> 32)) << 32) | dpp_u32<CTRL, ROWS>((unsigned)x);
+}
+__device__ __forceinline__ u64 lane63_u64(u64 x)
+{
+    return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), 63) << 32) |
+           (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, 63);
+}
+#define DPP_WAVE_STEPS(STEP)                                                                 \
+    STEP(0xB1, 0xf)  /* quad_perm [1,0,3,2] */ STEP(0x4E, 0xf) /* quad_perm [2,3,0,1] */     \
+    STEP(0x141, 0xf) /* row_half_mirror */     STEP(0x140, 0xf) /* row_mirror */             \
+    STEP(0x142, 0xa) /* row_bcast15 -> rows 1, 3 */ STEP(0x143, 0xc) /* row_bcast31 -> rows 2, 3 */
+
+// wave-wide minimum of a signed 64-bit key, valid in every lane
+__device__ __forceinline__ long long wave_min_i64(long long k)
+{
+#define STEP(C, R) { const long long o = (long long)dpp_u64<C, R>((u64)k); k = o < k ? o : k; }
+    DPP_WAVE_STEPS(STEP)
+#undef STEP
+    return (long long)lane63_u64((u64)k);
+}
+
+// wave-wide lexicographic minimum of (d, key), valid in every lane
+__device__ __forceinline__ void wave_argmin(double &d, u64 &key)
+{
+#define STEP(C, R) { const double od = __longlong_as_double((long long)dpp_u64<C, R>((u64)__double_as_longlong(d))); \
+                     const u64 ok = dpp_u64<C, R>(key);                                                                 \
+                     if (key_better(od, ok, d, key)) { d = od; key = ok; } }
+    DPP_WAVE_STEPS(STEP)
+#undef STEP
+    d = __longlong_as_double((long long)lane63_u64((u64)__double_as_longlong(d)));
+    key = lane63_u64(key);
+}
+
 // block-wide lexicographic min of (d, key); result valid in every thread.
 // scratch: 2 * 16 Partial-sized slots.
 __device__ __forceinline__ void block_argmin(double &d, u64 &key, Partial *scratch)
 {
-    for (int off = 32; off > 0; off >>= 1) {
-        double od = __shfl_xor(d, off);
-        u64 ok = __shfl_xor(key, off);
-        if (key_better(od, ok, d, key)) { d = od; key = ok; }
-    }
+    wave_argmin(d, key);
     const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
     if ((threadIdx.x & 63) == 0) { scratch[w].d = d; scratch[w].key = key; }
     __syncthreads();
@@ -1283,6 +1323,35 @@ __device__ __forceinline__ void best_finish(const Best &q, double &d, u64 &key)
     else { d = bd; key = ba < bb ? ((u64)(unsigned)ba << 32) | (unsigned)bb : ((u64)(unsigned)bb << 32) | (unsigned)ba; }
 }
 
+// The workgroup's best pair from the threads' running bests: (d, key) in every thread; true in the ONE thread that
+// holds that pair (a pair is evaluated exactly once; no thread when nothing was found).  Integer deltas: the packed
+// 64-bit key itself is reduced (one compare per step) and decoded once; doubles go through (delta, a, b).
+template <typename T, bool TABU>
+__device__ __forceinline__ bool block_best(const Best &q, double &d, u64 &key, Partial *scratch)
+{
+    constexpr bool PACKED = std::is_same<typename Elem<T>::acc, int>::value;
+    const u64 none = TABU ? KEY_NONE : 0;
+    if constexpr (PACKED) {
+        long long k = wave_min_i64(q.k);
+        const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+        if ((threadIdx.x & 63) == 0) scratch[w].key = (u64)k;
+        __syncthreads();
+        k = (long long)scratch[0].key;
+        for (int i = 1; i < nw; i++) { const long long o = (long long)scratch[i].key; k = o < k ? o : k; }
+        Best r = q;
+        r.k = k;
+        best_finish<T, TABU>(r, d, key);
+        return q.k == k && key != none;
+    } else {
+        double d_own;
+        u64 key_own;
+        best_finish<T, TABU>(q, d_own, key_own);
+        d = d_own; key = key_own;
+        block_argmin(d, key, scratch);
+        return key != none && key_own == key && d_own == d;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K2 "pipelined" sweep: the streaming form for rows that fit LDS three times (any cell type;
 // uint16 rows up to n ~ 27 000).  Workgroup g owns a run of cnt consecutive tour edges and
@@ -1426,8 +1495,7 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     STAMP(3);
     double d;
     u64 key;
-    best_finish<T, TABU>(q, d, key);
-    block_argmin(d, key, scratch);
+    block_best<T, TABU>(q, d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
         A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
@@ -1548,8 +1616,7 @@ __global__ void __launch_bounds__(1024) k_sweep_res(SweepArgs A)
     STAMP(3);
     double d;
     u64 key;
-    best_finish<T, TABU>(q, d, key);
-    block_argmin(d, key, scratch);
+    block_best<T, TABU>(q, d, key, scratch);
     if (tid == 0) {
         Partial o; o.d = d; o.key = key;
         A.S.partial[(size_t)t * A.S.pstride + blockIdx.x + A.g0] = o;
@@ -1966,16 +2033,13 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     }
 
     STAMP(3);
-    double d_own;
-    u64 key_own;
-    best_finish<T, false>(q, d_own, key_own);
-    double d = d_own;
-    u64 key = key_own;
-    block_argmin(d, key, scratch);
+    double d;
+    u64 key;
+    const bool winner = block_best<T, false>(q, d, key, scratch);
     if constexpr (PAY) {
         // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated
         // once): it leaves the record and takes part in the tour-wide atomic min
-        if (key != 0 && key_own == key && d_own == d) {
+        if (winner) {
             const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
             int own = -1, idx = 0;
 #pragma unroll
