@@ -59,6 +59,8 @@ enum {
                                    2 always, 0 never (separate sweep + apply launches) */
     TSPGPU_OPT_MATRIX_FREE = 11,/* 0 auto (matrix-free when a matrix row cannot sit in LDS), 1 always, 2 never;
                                    takes effect at the next tspgpu_build_costs */
+    TSPGPU_OPT_PIPE2 = 15,      /* one-launch-per-sweep kernel over streamed rows: 1 (default) two tour edges per barrier
+                                   interval where four rows fit LDS, 0 one edge per barrier over three row buffers */
     TSPGPU_OPT_NN_KERNEL = 14,  /* nearest-neighbour construction: 0 auto (the grid kernel whenever the weights come from
                                    the uploaded points, else the matrix kernel), 1 matrix / strided kernels always */
     TSPGPU_OPT_SWEEP_CAP = 13   /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
@@ -74,7 +76,8 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * 4 workgroups per tour, 5 LDS bytes per workgroup, 6 threads per workgroup,
  * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup,
  * 10 matrix-free mode in use, 11 one-launch-per-sweep path in use, 12 cells per side of the NN grid (0: the
- * grid kernel is not in use), 13 most points in one grid cell */
+ * grid kernel is not in use), 13 most points in one grid cell, 14 the fused streaming kernel takes two edges per
+ * barrier interval */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

@@ -317,6 +317,35 @@ def test_plan_overrides_keep_the_trajectory(eng, T, O, instances, golden, elem, 
         eng.set_option(T.OPT_BLOCK, 0); eng.set_option(T.OPT_WGS_PER_TOUR, 0); eng.set_option(T.OPT_DEPTH, 0)
 
 
+@pytest.mark.parametrize("pipe2", [1, 0])
+@pytest.mark.parametrize("elem", [1, 2, 3])
+@pytest.mark.parametrize("name", ["kroA100", "pr1002", "n1024_s1", "n200_s3"])
+def test_fused_streaming_forms_agree(eng, T, O, instances, golden, name, elem, pipe2):
+    """the one-launch-per-sweep kernel over streamed rows in its two forms -- two tour edges per barrier interval with
+    the row of a taken from registers (pipe_stream2, four LDS row buffers) and one edge per barrier (pipe_stream, three)
+    -- to the golden local optimum with the reference's move every sweep; odd and even run lengths via the workgroup count"""
+    xy, c = setup(eng, T, O, instances, name, elem, 2)
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    eng.set_option(T.OPT_FUSED, 2); eng.set_option(T.OPT_PIPE2, pipe2)
+    try:
+        for wgs in (0, 64, 37):
+            eng.set_option(T.OPT_WGS_PER_TOUR, wgs)
+            succ, nn_cost = eng.nn_tour(0)
+            eng.set_option(T.OPT_HISTORY, 4096)
+            cost, sweeps, rc = eng.two_opt(succ)
+            info = eng.info()
+            assert info["kernel"] == 2 and info["fused"] == 1 and info["pipe2"] == pipe2, info
+            assert rc == 0 and (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"]), (wgs, info)
+            a, b, d = eng.history(4096)
+            run = nn_cost
+            for i, want in enumerate(g["trace"]):
+                run += d[i]
+                assert run == want
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0); eng.set_option(T.OPT_WGS_PER_TOUR, 0)
+        eng.set_option(T.OPT_FUSED, 1); eng.set_option(T.OPT_PIPE2, 1)
+
+
 def _grid_instance(kind):
     if kind == "grid20":          # 400 lattice points: almost every delta value is shared by many pairs
         g = np.arange(20, dtype=np.float64)

@@ -1140,9 +1140,13 @@ constexpr int MASKED32 = 1 << 27;   // masked pair on the 32-bit key path: (x <<
 
 // bA: LDS row of a; bS: LDS row of succ a (ldsS: its LDS byte address).
 // BLOCKS: block ownership (symmetric matrix, plain 2-opt); else the index range (symmetric or not).
+// areg != nullptr (symmetric matrices only): the row of a comes from the REGISTERS that loaded it -- a thread's own
+// b's of chunk c are exactly the vector it fetched for chunk c of that row -- and c[a][succ a] = c[succ a][a] from the
+// LDS row of succ a; bA is not touched.
 template <typename T, int NCH, bool TABU, bool BLOCKS>
 __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, const T *bA, const unsigned char *bS, unsigned ldsS,
-                                              int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric)
+                                              int a, int am, int sa, int n, int ld, int BT, int tid, int wave_base, bool symmetric,
+                                              const typename Elem<T>::vec *areg = nullptr)
 {
     typedef typename Elem<T>::vec VT;
     typedef typename Elem<T>::acc AT;
@@ -1150,7 +1154,7 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
     constexpr bool PKS = sizeof(T) == 2;
     constexpr bool PACKED = std::is_same<AT, int>::value;
     const AT BIG = Elem<T>::big();
-    const AT d_a = (AT)bA[sa]; // c[a][succ a]
+    const AT d_a = areg ? (AT)reinterpret_cast<const T *>(bS)[a] : (AT)bA[sa]; // c[a][succ a]
     constexpr bool blocks = BLOCKS;
     const int NB = (n + 64 * V - 1) / (64 * V);
     const int blka = a / (64 * V);
@@ -1180,7 +1184,7 @@ __device__ __forceinline__ void sweep_step_as(Best &q, const BState<T, NCH> &B, 
         }
         const int b0 = (c * BT + tid) * V;
         // all LDS reads of the chunk first (lanes past the row read its last vector), then the arithmetic
-        const VT xa = *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
+        const VT xa = areg ? areg[c] : *reinterpret_cast<const VT *>(bA + min(b0, ld - V));
         auto valid = [&](int b) __attribute__((always_inline)) {
             asm volatile("" : "+v"(b));     // b < n is step-invariant: hoisted, it costs an SGPR pair per b
             if (blocks) return ((b > a) | !self) & (b < n) & (!TABU | ((b != am) & (b != sa)));
@@ -1438,6 +1442,72 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
     }
 
 #undef STAMP
+}
+
+// Streaming, second form (symmetric matrices, plain 2-opt, rows that fit LDS FOUR times): TWO tour edges per barrier
+// interval, and the row of a straight from the registers that loaded it.  In pipe_stream() a thread writes the vector
+// it fetched into LDS and reads the very same bytes back one step later as c[a][own b's] -- only the row of succ a
+// (random gather) has to be in LDS.  So a row lives in registers from its fetch until its step as "row of a", and in
+// LDS only for its step as "row of succ a":
+//     interval k, steps s = 2k and s+1:   rows s, s+1 in registers A0, A1 (row of a);  rows s+1, s+2 in LDS (gather)
+//     then: rows s+3, s+4 (registers X0, X1, in flight since the previous interval) are written into the two LDS
+//     buffers the previous interval gathered from, A0 <- N0 (row s+2), A1 <- X0, N0 <- X1, and X0, X1 are re-issued
+//     for rows s+5, s+6; ONE barrier.
+// Half the barriers and row-landing waits of pipe_stream(), two independent evaluation chains per interval, and a wave
+// that owns no pair of one step usually owns pairs of the other (ownership goes by block distance from a, and a and
+// succ a sit in different blocks): the 16 waves of a workgroup idle at the barrier far less.  c[a][succ a] is read as
+// c[succ a][a] from the gather row (symmetric), so the row of a is never needed in LDS.
+template <typename T, int NCH>
+__device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
+                                             int cnt, unsigned long long *stamp)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    const int n = A.n, ld = A.ld;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V;
+    const T *mat = static_cast<const T *>(A.mat);
+    VT A0[NCH], A1[NCH], N0[NCH], X0[NCH], X1[NCH];
+    auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        // branch-free; past the end of the run every lane re-reads one hot vector (same load count on every path)
+        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
+        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
+    };
+    auto land = [&](const VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        VT *dst = reinterpret_cast<VT *>(buf + (size_t)(r & 3) * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
+    };
+    issue(A0, 0); issue(A1, 1); issue(N0, 2); issue(X0, 3); issue(X1, 4);
+    land(A1, 1);
+    land(N0, 2);
+    __syncthreads();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto step = [&](int s, const VT(&Ar)[NCH]) __attribute__((always_inline)) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int slot = (s + 1) & 3;
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)slot * ld);
+        const unsigned ldsS = lds0 + (unsigned)(slot * ld) * (unsigned)sizeof(T);
+        if (A.ablate != 1) sweep_step_as<T, NCH, false, true>(q, B, nullptr, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true, Ar);
+    };
+    for (int s = 0; s < cnt; s += 2) {
+        step(s, A0);
+        if (s + 1 < cnt) step(s + 1, A1);
+        if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
+        if (s + 3 <= cnt) land(X0, s + 3);
+        if (s + 4 <= cnt) land(X1, s + 4);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { A0[c] = N0[c]; A1[c] = X0[c]; N0[c] = X1[c]; }
+        issue(X0, s + 5);
+        issue(X1, s + 6);
+        __syncthreads();
+        if (stamp && tid == 0 && s < 24) stamp[9 + s] = wall_clock64();
+    }
 }
 
 template <typename T, int NCH, int D, bool TABU>
@@ -1734,7 +1804,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     // LDS: (P+1) rows, or the 3 rotating row buffers | nodes[-1 .. P] | (16 spare bytes) | reduction scratch
     T *rows = reinterpret_cast<T *>(smem);
-    const size_t rows_bytes = (size_t)(D > 0 ? 3 : A.P + 1) * ld * sizeof(T);
+    const size_t rows_bytes = (size_t)(D == 4 ? 4 : D > 0 ? 3 : A.P + 1) * ld * sizeof(T);
     int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
     Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4 + (D > 0 ? 16 : 0));
 
@@ -1986,7 +2056,9 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     Best q;
     best_init<false>(q);
-    if constexpr (D > 0) {
+    if constexpr (D == 4) {
+        pipe_stream2<T, NCH>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, stamp);
+    } else if constexpr (D > 0) {
         pipe_stream<T, NCH, D, false>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, 0, 0, stamp);
     } else {
     // every row of the run in flight at once
@@ -2613,6 +2685,9 @@ struct tspgpu_ctx {
     bool plan_tabu_fits = true;   // the tabu variants' extra n + 32 LDS bytes fit beside the rows
     unsigned long long *d_stamps = nullptr;
     size_t plan_lds = 0;
+    size_t plan_lds_fused = 0;  // dynamic LDS of the one-launch-per-sweep kernel (four row buffers in its two-edge streaming form)
+    bool plan_pipe2 = false;    // the fused pipelined kernel streams two tour edges per barrier interval (pipe_stream2)
+    int opt_pipe2 = 1;          // 1 = use that form where four rows fit LDS, 0 = never
 
     Fused F{};                 // fused path state (allocated on first use, capacity fcap)
     int fcap = 0;
@@ -2863,15 +2938,17 @@ static const void *res_kernel(int elem, int nch, bool tabu)
 }
 
 template <typename T, int NCH, int D> static const void *fused_fn() { return (const void *)k_sweep_fused<T, NCH, 8, D>; }
-// kernel 3: resident rows (nch 1, 2); kernel 2: streamed rows, depth 2 (nch 1, 2)
-static const void *fused_kernel(int elem, int nch, int kernel)
+// kernel 3: resident rows (nch 1, 2); kernel 2: streamed rows (nch 1, 2) -- two edges per barrier interval over four
+// LDS row buffers (pipe_stream2) when `pipe2`, else one edge per barrier over three (pipe_stream, register depth 2)
+static const void *fused_kernel(int elem, int nch, int kernel, bool pipe2)
 {
     const void *fn = nullptr;
     if (kernel == 3) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 0>() : nch == 2 ? fused_fn<T, 2, 0>() : nullptr);
     else if (kernel == 2) {
         // (three uint16 chunks per thread, n > 16 384: the fused prologue no longer fits the register
         // budget next to the per-b state -- measured 1.7x slower than sweep + apply on d18512)
-        ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
+        if (pipe2) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 4>() : nch == 2 ? fused_fn<T, 2, 4>() : nullptr);
+        else ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
     }
     return fn;
 }
@@ -2993,6 +3070,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             }
             while (!pipe_fits(BT, P) && G < MAX_WGS_PER_TOUR) { G *= 2; P = (n + G - 1) / G; G = (n + P - 1) / P; }
             ctx->plan_lds = 3 * row + (size_t)((P + 2 + 3) & ~3) * 4 + 16 + 16 * sizeof(Partial) + 64;
+            ctx->plan_pipe2 = ctx->opt_pipe2 && nch <= 2 && P >= 2 && ctx->plan_lds + row <= ctx->lds_max;
         }
     }
     if (kernel == 1) {
@@ -3005,9 +3083,11 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     }
     if (n > 64 * 1024) return fail(ctx, E_EXHAUSTED, "n=%d exceeds the matrix-mode limit", n);
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
+    if (kernel != 2) ctx->plan_pipe2 = false;
+    ctx->plan_lds_fused = ctx->plan_lds + (ctx->plan_pipe2 ? row : 0);
     // raise the dynamic-LDS cap of the kernels we are going to launch
-    if (const void *ff = fused_kernel(ctx->elem, nch, kernel))
-        HIP_TRY(hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds));
+    if (const void *ff = fused_kernel(ctx->elem, nch, kernel, ctx->plan_pipe2))
+        HIP_TRY(hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_fused));
     for (int tabu = 0; tabu < 2; tabu++) {
         const void *fn = kernel == 3 ? res_kernel(ctx->elem, nch, tabu)
                        : kernel == 2 ? pipe_kernel(ctx->elem, nch, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
@@ -3140,10 +3220,10 @@ static int launch_fused(tspgpu_ctx *ctx, int slot0, int ntours, int parity)
     A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
     A.pts = ctx->d_pts; A.spts = nullptr; A.kind = ctx->kind;
     A.F = ctx->F; A.parity = parity; A.hist = ctx->hist;
-    const void *fn = fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel);
+    const void *fn = fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2);
     if (!fn) return fail(ctx, E_INTERNAL, "no one-launch-per-sweep instance for kernel %d, %d chunks", ctx->plan_kernel, ctx->plan_NCH);
     void *args[] = {&A};
-    HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds, ctx->stream));
+    HIP_TRY(hipLaunchKernel(fn, dim3(ctx->plan_G, ntours), dim3(ctx->plan_BT), args, ctx->plan_lds_fused, ctx->stream));
     return E_OK;
 }
 
@@ -3313,7 +3393,7 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
     // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
     // tour at once and the leaner sweep wins (measured 7.0e11 vs 5.0e11 evals/s at 64 tours).
-    if (!tabu && ctx->symmetric && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel) &&
+    if (!tabu && ctx->symmetric && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2) &&
         (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
         return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
@@ -3681,6 +3761,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
+    case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
     case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
     case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
@@ -3703,7 +3784,8 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 8: return ctx->cus;
     case 9: return ctx->plan_D;
     case 10: return ctx->otf ? 1 : 0;
-    case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel)) ? 1 : 0;
+    case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2)) ? 1 : 0;
+    case 14: return ctx->plan_pipe2 ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
