@@ -1457,7 +1457,7 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
 // that owns no pair of one step usually owns pairs of the other (ownership goes by block distance from a, and a and
 // succ a sit in different blocks): the 16 waves of a workgroup idle at the barrier far less.  c[a][succ a] is read as
 // c[succ a][a] from the gather row (symmetric), so the row of a is never needed in LDS.
-template <typename T, int NCH>
+template <typename T, int NCH, int PAIRS>
 __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
                                              int cnt, unsigned long long *stamp)
 {
@@ -1467,9 +1467,14 @@ __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const 
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nvec = ld / V;
     const T *mat = static_cast<const T *>(A.mat);
-    VT A0[NCH], A1[NCH], N0[NCH], X0[NCH], X1[NCH];
+    // A0, A1: rows of a of the two steps of an interval; N0: the row after them (already gathered from, needed as a row
+    // of a next interval); X (and, PAIRS = 2, Y): pairs of rows in flight, landed PAIRS intervals after their issue --
+    // with two pairs up to four rows (4 x 32 KB at n=4096 f64) of a workgroup are on their way at any time (uint16 rows
+    // with two chunks per thread keep one pair: seven register sets next to 16 b's of state would spill)
+    VT A0[NCH], A1[NCH], N0[NCH], X0[NCH], X1[NCH], Y0[PAIRS == 2 ? NCH : 1], Y1[PAIRS == 2 ? NCH : 1];
     auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
-        // branch-free; past the end of the run every lane re-reads one hot vector (same load count on every path)
+        // branch-free; past the end of the run every lane re-reads one hot vector (same load count on every path, which
+        // lets hipcc place exact counted vmcnt waits in front of the LDS writes)
         const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
         const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
 #pragma unroll
@@ -1481,6 +1486,7 @@ __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const 
         for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
     };
     issue(A0, 0); issue(A1, 1); issue(N0, 2); issue(X0, 3); issue(X1, 4);
+    if constexpr (PAIRS == 2) { issue(Y0, 5); issue(Y1, 6); }
     land(A1, 1);
     land(N0, 2);
     __syncthreads();
@@ -1495,18 +1501,33 @@ __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const 
         const unsigned ldsS = lds0 + (unsigned)(slot * ld) * (unsigned)sizeof(T);
         if (A.ablate != 1) sweep_step_as<T, NCH, false, true>(q, B, nullptr, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true, Ar);
     };
-    for (int s = 0; s < cnt; s += 2) {
+    // one interval: steps s, s+1; rows s+3, s+4 (pair P, issued two intervals ago) into the LDS buffers the previous
+    // interval gathered from; registers rotate; the pair is re-issued for the rows four intervals' worth ahead
+    auto interval = [&](int s, VT(&P0)[NCH], VT(&P1)[NCH], auto tail_tag) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
         step(s, A0);
-        if (s + 1 < cnt) step(s + 1, A1);
+        if (!TAIL || s + 1 < cnt) step(s + 1, A1);
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
-        if (s + 3 <= cnt) land(X0, s + 3);
-        if (s + 4 <= cnt) land(X1, s + 4);
+        if (!TAIL || s + 3 <= cnt) land(P0, s + 3);
+        if (!TAIL || s + 4 <= cnt) land(P1, s + 4);
 #pragma unroll
-        for (int c = 0; c < NCH; c++) { A0[c] = N0[c]; A1[c] = X0[c]; N0[c] = X1[c]; }
-        issue(X0, s + 5);
-        issue(X1, s + 6);
+        for (int c = 0; c < NCH; c++) { A0[c] = N0[c]; A1[c] = P0[c]; N0[c] = P1[c]; }
+        issue(P0, s + 3 + 2 * PAIRS);
+        issue(P1, s + 4 + 2 * PAIRS);
         __syncthreads();
         if (stamp && tid == 0 && s < 24) stamp[9 + s] = wall_clock64();
+    };
+    int s = 0;
+    if constexpr (PAIRS == 2) {
+        for (; s + 4 <= cnt; s += 4) {      // unconditional body: exact vmcnt accounting
+            interval(s, X0, X1, std::false_type{});
+            interval(s + 2, Y0, Y1, std::false_type{});
+        }
+        if (s < cnt) interval(s, X0, X1, std::true_type{});
+        if (s + 2 < cnt) interval(s + 2, Y0, Y1, std::true_type{});
+    } else {
+        for (; s + 2 <= cnt; s += 2) interval(s, X0, X1, std::false_type{});
+        if (s < cnt) interval(s, X0, X1, std::true_type{});
     }
 }
 
@@ -1804,7 +1825,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     // LDS: (P+1) rows, or the 3 rotating row buffers | nodes[-1 .. P] | (16 spare bytes) | reduction scratch
     T *rows = reinterpret_cast<T *>(smem);
-    const size_t rows_bytes = (size_t)(D == 4 ? 4 : D > 0 ? 3 : A.P + 1) * ld * sizeof(T);
+    const size_t rows_bytes = (size_t)(D >= 4 ? 4 : D > 0 ? 3 : A.P + 1) * ld * sizeof(T);
     int *nodes = reinterpret_cast<int *>(smem + rows_bytes) + 1;
     Partial *scratch = reinterpret_cast<Partial *>(smem + rows_bytes + (size_t)((A.P + 2 + 3) & ~3) * 4 + (D > 0 ? 16 : 0));
 
@@ -2056,8 +2077,8 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     Best q;
     best_init<false>(q);
-    if constexpr (D == 4) {
-        pipe_stream2<T, NCH>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, stamp);
+    if constexpr (D >= 4) {      // 4: one pair of rows in flight, 5: two
+        pipe_stream2<T, NCH, D - 3>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, stamp);
     } else if constexpr (D > 0) {
         pipe_stream<T, NCH, D, false>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, 0, 0, stamp);
     } else {
@@ -2947,7 +2968,8 @@ static const void *fused_kernel(int elem, int nch, int kernel, bool pipe2)
     else if (kernel == 2) {
         // (three uint16 chunks per thread, n > 16 384: the fused prologue no longer fits the register
         // budget next to the per-b state -- measured 1.7x slower than sweep + apply on d18512)
-        if (pipe2) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 4>() : nch == 2 ? fused_fn<T, 2, 4>() : nullptr);
+        if (pipe2 && elem == TSPGPU_ELEM_U16) fn = nch == 1 ? fused_fn<u16, 1, 5>() : nch == 2 ? fused_fn<u16, 2, 4>() : nullptr;
+        else if (pipe2) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 5>() : nch == 2 ? fused_fn<T, 2, 5>() : nullptr);
         else ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
     }
     return fn;
