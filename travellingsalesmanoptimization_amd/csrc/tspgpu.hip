@@ -2968,8 +2968,11 @@ static const void *fused_kernel(int elem, int nch, int kernel, bool pipe2)
     else if (kernel == 2) {
         // (three uint16 chunks per thread, n > 16 384: the fused prologue no longer fits the register
         // budget next to the per-b state -- measured 1.7x slower than sweep + apply on d18512)
+        // rows in flight (4 = one pair, 5 = two): measured at n=4096 -- f64 30.9 us with one pair, 33.0 with two (already at
+        // 5.6 TB/s of the ~6.1 TB/s a CU's load path sustains; more requests only queue); int32 20.9 / 20.5
         if (pipe2 && elem == TSPGPU_ELEM_U16) fn = nch == 1 ? fused_fn<u16, 1, 5>() : nch == 2 ? fused_fn<u16, 2, 4>() : nullptr;
-        else if (pipe2) ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 5>() : nch == 2 ? fused_fn<T, 2, 5>() : nullptr);
+        else if (pipe2 && elem == TSPGPU_ELEM_F64) fn = nch == 1 ? fused_fn<double, 1, 4>() : nch == 2 ? fused_fn<double, 2, 4>() : nullptr;
+        else if (pipe2) fn = nch == 1 ? fused_fn<int, 1, 5>() : nch == 2 ? fused_fn<int, 2, 5>() : nullptr;
         else ELEM_SWITCH(elem, T, fn = nch == 1 ? fused_fn<T, 1, 2>() : nch == 2 ? fused_fn<T, 2, 2>() : nullptr);
     }
     return fn;
