@@ -1544,11 +1544,12 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
     const int tid = threadIdx.x, BT = blockDim.x;
     const int nvec = ld / V; // 16-byte vectors per row
 
-    // LDS: 3 row buffers | nodes[-1 .. P] | 16 spare bytes | reduction scratch
+    // LDS: 3 row buffers (4 in the two-edge form, D == 9) | nodes[-1 .. P] | 16 spare bytes | reduction scratch
+    constexpr int NBUF = D == 9 ? 4 : 3;
     T *buf = reinterpret_cast<T *>(smem);
-    int *nodes = reinterpret_cast<int *>(smem + (size_t)3 * ld * sizeof(T)) + 1; // nodes[-1] = node before the run
+    int *nodes = reinterpret_cast<int *>(smem + (size_t)NBUF * ld * sizeof(T)) + 1; // nodes[-1] = node before the run
     const size_t nodes_bytes = (size_t)((A.P + 2 + 3) & ~3) * 4;
-    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)3 * ld * sizeof(T) + nodes_bytes + 16);
+    Partial *scratch = reinterpret_cast<Partial *>(smem + (size_t)NBUF * ld * sizeof(T) + nodes_bytes + 16);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;   // LDS byte address of the row buffers
 
     const T *mat = static_cast<const T *>(A.mat);
@@ -1581,7 +1582,8 @@ __global__ void __launch_bounds__(1024) k_sweep_pipe(SweepArgs A)
 
     Best q;
     best_init<TABU>(q);
-    pipe_stream<T, NCH, D, TABU>(q, A, B, buf, nodes, lds0, cnt, iter, tenure, stamp);
+    if constexpr (D == 9) pipe_stream2<T, NCH, 1>(q, A, B, buf, nodes, lds0, cnt, stamp);   // symmetric, plain 2-opt (host)
+    else pipe_stream<T, NCH, D, TABU>(q, A, B, buf, nodes, lds0, cnt, iter, tenure, stamp);
 
     STAMP(3);
     double d;
@@ -2708,6 +2710,7 @@ struct tspgpu_ctx {
     size_t plan_lds = 0;
     size_t plan_lds_fused = 0;  // dynamic LDS of the one-launch-per-sweep kernel (four row buffers in its two-edge streaming form)
     bool plan_pipe2 = false;    // the fused pipelined kernel streams two tour edges per barrier interval (pipe_stream2)
+    bool plan_pipe2_sweep = false;   // ... and so does the plain pipelined sweep (batches; symmetric, not tabu)
     int opt_pipe2 = 1;          // 1 = use that form where four rows fit LDS, 0 = never
 
     Fused F{};                 // fused path state (allocated on first use, capacity fcap)
@@ -2922,6 +2925,15 @@ static int pipe_depth(int nch, int want) {
     return std::min(d, dmax);
 }
 
+// depth 9 = the two-edge form (pipe_stream2, four LDS row buffers): symmetric matrices, plain 2-opt, nch <= 3
+static const void *pipe2_kernel(int elem, int nch)
+{
+    const void *fn = nullptr;
+    ELEM_SWITCH(elem, T, fn = nch == 1 ? pipe_fn<T, 1, 9, false>() : nch == 2 ? pipe_fn<T, 2, 9, false>() : nullptr);
+    if (elem == TSPGPU_ELEM_U16 && nch == 3) fn = pipe_fn<u16, 3, 9, false>();
+    return fn;
+}
+
 static const void *pipe_kernel(int elem, int nch, int depth, bool tabu)
 {
 #define PK(T, N, DD) (tabu ? pipe_fn<T, N, DD, true>() : pipe_fn<T, N, DD, false>())
@@ -3096,6 +3108,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             while (!pipe_fits(BT, P) && G < MAX_WGS_PER_TOUR) { G *= 2; P = (n + G - 1) / G; G = (n + P - 1) / P; }
             ctx->plan_lds = 3 * row + (size_t)((P + 2 + 3) & ~3) * 4 + 16 + 16 * sizeof(Partial) + 64;
             ctx->plan_pipe2 = ctx->opt_pipe2 && nch <= 2 && P >= 2 && ctx->plan_lds + row <= ctx->lds_max;
+            ctx->plan_pipe2_sweep = ctx->opt_pipe2 && pipe2_kernel(ctx->elem, nch) && P >= 2 && ctx->plan_lds + row <= ctx->lds_max;
         }
     }
     if (kernel == 1) {
@@ -3108,8 +3121,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
     }
     if (n > 64 * 1024) return fail(ctx, E_EXHAUSTED, "n=%d exceeds the matrix-mode limit", n);
     ctx->plan_kernel = kernel; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = BT; ctx->plan_NCH = nch; ctx->plan_T = ntours;
-    if (kernel != 2) ctx->plan_pipe2 = false;
+    if (kernel != 2) ctx->plan_pipe2 = ctx->plan_pipe2_sweep = false;
     ctx->plan_lds_fused = ctx->plan_lds + (ctx->plan_pipe2 ? row : 0);
+    if (ctx->plan_pipe2_sweep)
+        HIP_TRY(hipFuncSetAttribute(pipe2_kernel(ctx->elem, nch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(ctx->plan_lds + row)));
     // raise the dynamic-LDS cap of the kernels we are going to launch
     if (const void *ff = fused_kernel(ctx->elem, nch, kernel, ctx->plan_pipe2))
         HIP_TRY(hipFuncSetAttribute(ff, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->plan_lds_fused));
@@ -3158,11 +3173,16 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
     }
     const void *fn = ctx->plan_kernel == 3 ? res_kernel(ctx->elem, ctx->plan_NCH, tabu)
                    : ctx->plan_kernel == 2 ? pipe_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_D, tabu) : simple_kernel(ctx->elem, tabu);
+    // (the two-edge streaming form replaces the pipelined kernel below when it applies)
     // tabu: n + 32 verdict bytes behind everything else in the dynamic LDS
     if (tabu && ctx->plan_kernel != 1 && !ctx->plan_tabu_fits)
         return fail(ctx, E_EXHAUSTED, "tabu sweep: the rows leave no room for %d verdict bytes in LDS (use TSPGPU_OPT_KERNEL=1 or the matrix-free mode)", ctx->n + 32);
     A.tabu_lds = (int)((ctx->plan_lds + 15) & ~(size_t)15);
-    const size_t lds = tabu && ctx->plan_kernel != 1 ? (size_t)A.tabu_lds + ctx->n + 32 : ctx->plan_lds;
+    size_t lds = tabu && ctx->plan_kernel != 1 ? (size_t)A.tabu_lds + ctx->n + 32 : ctx->plan_lds;
+    if (ctx->plan_kernel == 2 && ctx->plan_pipe2_sweep && !tabu && ctx->symmetric) {
+        fn = pipe2_kernel(ctx->elem, ctx->plan_NCH);
+        lds = ctx->plan_lds + (size_t)ctx->ld * elem_size(ctx->elem);
+    }
     void *args[] = {&A};
     HIP_TRY(hipLaunchKernel(fn, dim3(G, ntours), dim3(ctx->plan_BT), args, lds, ctx->stream));
     return E_OK;
@@ -3810,7 +3830,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 9: return ctx->plan_D;
     case 10: return ctx->otf ? 1 : 0;
     case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2)) ? 1 : 0;
-    case 14: return ctx->plan_pipe2 ? 1 : 0;
+    case 14: return (ctx->plan_pipe2 || ctx->plan_pipe2_sweep) ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
