@@ -57,7 +57,7 @@ def main():
                 traffic[key] = rd + wrb
     with open(os.path.join(root, f"{rnd}_pmc_hbm_traffic.csv"), "w") as out:
         out.write(f"# {rnd} -- rocprofv3 PMC passes (separate --pmc runs, no tracing domains)\n"
-                  "# command: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --n <n> --steps 1 --warmup 0 --cpu-sweeps 0 --no-other --batch-starts 0 --elem <e>\n"
+                  "# command: rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --n <n> --steps 1 --warmup 0 --lean --elem <e>\n"
                   "# FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 1/2 of a wide coalesced read (MI355X_MICROARCH.md, HBM) -> x2\n"
                   "# means are over LIVE launches (launches after the search finished exit at once and are excluded)\n"
                   "n,elem,kernel,live_launches,FETCH_SIZE_KiB_mean,WRITE_SIZE_KiB_mean,hbm_read_bytes_corrected,hbm_write_bytes,algorithmic_bytes,read_over_algorithmic\n")
