@@ -1981,24 +1981,6 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         nodes[ndir > 0 ? j : cnt - j] = v;
         if (j >= 0 && j < cnt) A.F.ord[wr][tn + p] = v;
     }
-    __syncthreads(); // nodes[] visible
-    // Resident body: every row of the run in flight NOW, before the state derivation below -- the derivation is ~100
-    // vector instructions per thread that need nothing from memory any more, so they run under the rows' latency
-    // instead of in front of it.
-    // (one chunk per thread only: with two, nine rows of two vectors next to the derivation's registers would spill)
-    VT R[D == 0 ? PMAX + 1 : 1][NCH];
-    constexpr bool EARLY_ROWS = D == 0 && NCH == 1;
-    auto issue_rows = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r <= (D == 0 ? PMAX : 0); r++) {
-            if (r <= cnt && A.ablate != 2) {
-                const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[r] * ld);
-#pragma unroll
-                for (int c = 0; c < NCH; c++) R[r][c] = src[min(c * BT + tid, nvec - 1)];
-            }
-        }
-    };
-    if constexpr (EARLY_ROWS) { if (!last) issue_rows(); }
 
     // per-thread state of the owned b's on the NEW state, from coalesced loads of the old one:
     // a node inside the reversed range swaps its left/right neighbour (and edge cost); the four
@@ -2091,6 +2073,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         }
     }
     if (last) return;   // sweep cap reached: the move is applied and recorded, no further sweep (the next launch raises `done`)
+    __syncthreads(); // nodes[] visible
     if (stamp && tid == 0) { stamp[0] = t_entry; stamp[5] = t_red; }
     STAMP(1);
 
@@ -2101,8 +2084,17 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     } else if constexpr (D > 0) {
         pipe_stream<T, NCH, D, false>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, 0, 0, stamp);
     } else {
-    // every row of the run in flight at once (one chunk per thread: since before the state derivation)
-    if constexpr (!EARLY_ROWS) issue_rows();
+    // every row of the run in flight at once
+    VT R[PMAX + 1][NCH];
+#pragma unroll
+    for (int r = 0; r <= PMAX; r++) {
+        if (r <= cnt && A.ablate != 2) {
+            const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[r] * ld);
+#pragma unroll
+            for (int c = 0; c < NCH; c++) R[r][c] = src[min(c * BT + tid, nvec - 1)];
+        }
+    }
+
     const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_u8 *)smem;
 
