@@ -1457,99 +1457,78 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
 // that owns no pair of one step usually owns pairs of the other (ownership goes by block distance from a, and a and
 // succ a sit in different blocks): the 16 waves of a workgroup idle at the barrier far less.  c[a][succ a] is read as
 // c[succ a][a] from the gather row (symmetric), so the row of a is never needed in LDS.
-template <typename T, int NCH, int PAIRS> struct Pipe2 {
-    typedef typename Elem<T>::vec VT;
-    static constexpr int V = Elem<T>::V;
-    static constexpr int FIRST = 3 + 2 * PAIRS;      // rows fetched before the first interval
-    // A0, A1: rows of a of the two steps of an interval; N0: the row after them (already gathered from, needed as a row
-    // of a next interval); X (and, PAIRS = 2, Y): pairs of rows in flight, landed PAIRS intervals after their issue --
-    // with two pairs up to four rows of a workgroup are on their way at any time (uint16 rows with two chunks per
-    // thread keep one pair: seven register sets next to 16 b's of state would spill)
-    VT A0[NCH], A1[NCH], N0[NCH], X0[NCH], X1[NCH], Y0[PAIRS == 2 ? NCH : 1], Y1[PAIRS == 2 ? NCH : 1];
-
-    // branch-free; past the end of the run every lane re-reads one hot vector (same load count on every path, which
-    // lets hipcc place exact counted vmcnt waits in front of the LDS writes)
-    __device__ __forceinline__ static void issue(VT (&Rs)[NCH], const SweepArgs &A, const int *nodes, int cnt, int r)
-    {
-        const int BT = blockDim.x, tid = threadIdx.x, nvec = A.ld / V;
-        const T *mat = static_cast<const T *>(A.mat);
-        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * A.ld);
-        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
-#pragma unroll
-        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
-    }
-    // the rows the first interval needs (0 .. FIRST-1), from `nodes` (entries 0 .. min(cnt, FIRST-1) are read)
-    __device__ __forceinline__ void issue_first(const SweepArgs &A, const int *nodes, int cnt)
-    {
-        issue(A0, A, nodes, cnt, 0); issue(A1, A, nodes, cnt, 1); issue(N0, A, nodes, cnt, 2);
-        issue(X0, A, nodes, cnt, 3); issue(X1, A, nodes, cnt, 4);
-        if constexpr (PAIRS == 2) { issue(Y0, A, nodes, cnt, 5); issue(Y1, A, nodes, cnt, 6); }
-    }
-
-    // the sweep over the run; the first rows are in flight already (issue_first)
-    __device__ __forceinline__ void run(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0, int cnt,
-                                        unsigned long long *stamp)
-    {
-        const int n = A.n, ld = A.ld;
-        const int tid = threadIdx.x, BT = blockDim.x;
-        const int nvec = ld / V;
-        auto land = [&](const VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
-            VT *dst = reinterpret_cast<VT *>(buf + (size_t)(r & 3) * ld);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
-        };
-        land(A1, 1);
-        land(N0, 2);
-        __syncthreads();
-        if (stamp && tid == 0) stamp[2] = wall_clock64();
-        const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-        auto step = [&](int s, const VT(&Ar)[NCH]) __attribute__((always_inline)) {
-            const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
-            const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
-            const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
-            const int slot = (s + 1) & 3;
-            const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)slot * ld);
-            const unsigned ldsS = lds0 + (unsigned)(slot * ld) * (unsigned)sizeof(T);
-            if (A.ablate != 1) sweep_step_as<T, NCH, false, true>(q, B, nullptr, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true, Ar);
-        };
-        // one interval: steps s, s+1; rows s+3, s+4 (pair P, issued PAIRS intervals ago) into the LDS buffers the previous
-        // interval gathered from; registers rotate; the pair is re-issued for the rows PAIRS intervals ahead
-        auto interval = [&](int s, VT(&P0)[NCH], VT(&P1)[NCH], auto tail_tag) __attribute__((always_inline)) {
-            constexpr bool TAIL = decltype(tail_tag)::value;
-            step(s, A0);
-            if (!TAIL || s + 1 < cnt) step(s + 1, A1);
-            if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
-            if (!TAIL || s + 3 <= cnt) land(P0, s + 3);
-            if (!TAIL || s + 4 <= cnt) land(P1, s + 4);
-#pragma unroll
-            for (int c = 0; c < NCH; c++) { A0[c] = N0[c]; A1[c] = P0[c]; N0[c] = P1[c]; }
-            issue(P0, A, nodes, cnt, s + 3 + 2 * PAIRS);
-            issue(P1, A, nodes, cnt, s + 4 + 2 * PAIRS);
-            __syncthreads();
-            if (stamp && tid == 0 && s < 24) stamp[9 + s] = wall_clock64();
-        };
-        int s = 0;
-        if constexpr (PAIRS == 2) {
-            for (; s + 4 <= cnt; s += 4) {      // unconditional body: exact vmcnt accounting
-                interval(s, X0, X1, std::false_type{});
-                interval(s + 2, Y0, Y1, std::false_type{});
-            }
-            if (s < cnt) interval(s, X0, X1, std::true_type{});
-            if (s + 2 < cnt) interval(s + 2, Y0, Y1, std::true_type{});
-        } else {
-            for (; s + 2 <= cnt; s += 2) interval(s, X0, X1, std::false_type{});
-            if (s < cnt) interval(s, X0, X1, std::true_type{});
-        }
-    }
-};
-
 template <typename T, int NCH, int PAIRS>
 __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
                                              int cnt, unsigned long long *stamp)
 {
-    Pipe2<T, NCH, PAIRS> P;
-    P.issue_first(A, nodes, cnt);
-    P.run(q, A, B, buf, nodes, lds0, cnt, stamp);
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    const int n = A.n, ld = A.ld;
+    const int tid = threadIdx.x, BT = blockDim.x;
+    const int nvec = ld / V;
+    const T *mat = static_cast<const T *>(A.mat);
+    // A0, A1: rows of a of the two steps of an interval; N0: the row after them (already gathered from, needed as a row
+    // of a next interval); X (and, PAIRS = 2, Y): pairs of rows in flight, landed PAIRS intervals after their issue --
+    // with two pairs up to four rows (4 x 32 KB at n=4096 f64) of a workgroup are on their way at any time (uint16 rows
+    // with two chunks per thread keep one pair: seven register sets next to 16 b's of state would spill)
+    VT A0[NCH], A1[NCH], N0[NCH], X0[NCH], X1[NCH], Y0[PAIRS == 2 ? NCH : 1], Y1[PAIRS == 2 ? NCH : 1];
+    auto issue = [&](VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        // branch-free; past the end of the run every lane re-reads one hot vector (same load count on every path, which
+        // lets hipcc place exact counted vmcnt waits in front of the LDS writes)
+        const VT *src = reinterpret_cast<const VT *>(mat + (size_t)nodes[min(r, cnt)] * ld);
+        const int lim = (r <= cnt && A.ablate != 2) ? nvec - 1 : 0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++) Rs[c] = src[min(c * BT + tid, lim)];
+    };
+    auto land = [&](const VT(&Rs)[NCH], int r) __attribute__((always_inline)) {
+        VT *dst = reinterpret_cast<VT *>(buf + (size_t)(r & 3) * ld);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) dst[min(c * BT + tid, nvec - 1)] = Rs[c];
+    };
+    issue(A0, 0); issue(A1, 1); issue(N0, 2); issue(X0, 3); issue(X1, 4);
+    if constexpr (PAIRS == 2) { issue(Y0, 5); issue(Y1, 6); }
+    land(A1, 1);
+    land(N0, 2);
+    __syncthreads();
+    if (stamp && tid == 0) stamp[2] = wall_clock64();
+    const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+    auto step = [&](int s, const VT(&Ar)[NCH]) __attribute__((always_inline)) {
+        const int a = __builtin_amdgcn_readfirstlane(nodes[s]);
+        const int am = __builtin_amdgcn_readfirstlane(nodes[s - 1]);
+        const int sa = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+        const int slot = (s + 1) & 3;
+        const unsigned char *bS = reinterpret_cast<const unsigned char *>(buf + (size_t)slot * ld);
+        const unsigned ldsS = lds0 + (unsigned)(slot * ld) * (unsigned)sizeof(T);
+        if (A.ablate != 1) sweep_step_as<T, NCH, false, true>(q, B, nullptr, bS, ldsS, a, am, sa, n, ld, BT, tid, wave_base, true, Ar);
+    };
+    // one interval: steps s, s+1; rows s+3, s+4 (pair P, issued two intervals ago) into the LDS buffers the previous
+    // interval gathered from; registers rotate; the pair is re-issued for the rows four intervals' worth ahead
+    auto interval = [&](int s, VT(&P0)[NCH], VT(&P1)[NCH], auto tail_tag) __attribute__((always_inline)) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        step(s, A0);
+        if (!TAIL || s + 1 < cnt) step(s + 1, A1);
+        if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
+        if (!TAIL || s + 3 <= cnt) land(P0, s + 3);
+        if (!TAIL || s + 4 <= cnt) land(P1, s + 4);
+#pragma unroll
+        for (int c = 0; c < NCH; c++) { A0[c] = N0[c]; A1[c] = P0[c]; N0[c] = P1[c]; }
+        issue(P0, s + 3 + 2 * PAIRS);
+        issue(P1, s + 4 + 2 * PAIRS);
+        __syncthreads();
+        if (stamp && tid == 0 && s < 24) stamp[9 + s] = wall_clock64();
+    };
+    int s = 0;
+    if constexpr (PAIRS == 2) {
+        for (; s + 4 <= cnt; s += 4) {      // unconditional body: exact vmcnt accounting
+            interval(s, X0, X1, std::false_type{});
+            interval(s + 2, Y0, Y1, std::false_type{});
+        }
+        if (s < cnt) interval(s, X0, X1, std::true_type{});
+        if (s + 2 < cnt) interval(s + 2, Y0, Y1, std::true_type{});
+    } else {
+        for (; s + 2 <= cnt; s += 2) interval(s, X0, X1, std::false_type{});
+        if (s < cnt) interval(s, X0, X1, std::true_type{});
+    }
 }
 
 template <typename T, int NCH, int D, bool TABU>
@@ -1907,21 +1886,6 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int cnt = min(A.P, n - p0);
     int node_spec = 0;
     if (tid <= cnt + 1) node_spec = ord_o[wrap(p0 + tid - 1, n)];
-    // Streamed rows (two-edge form): the first rows of the run are requested NOW, on the guess that the move leaves
-    // this run alone (same nodes, same direction: true for all but a few workgroups per sweep) -- the partial
-    // reduction / record fetch and the state derivation below then run under their latency instead of in front of
-    // it.  A workgroup whose run did change requests its rows again once it knows them; the stale loads land in
-    // registers that are rewritten (loads return in order).
-    Pipe2<T, NCH, (D >= 4 ? D - 3 : 1)> P2;
-    int *nspec = reinterpret_cast<int *>(scratch + 16);      // 16 ints of slack behind the reduction scratch
-    if constexpr (D >= 4) {
-        if (tid <= cnt + 1) {
-            const int j = tid - 1, i = dir_o > 0 ? j : cnt - j;          // position in the run if the direction stays
-            if ((unsigned)i < 8u) nspec[i] = node_spec;
-        }
-        __syncthreads();
-        P2.issue_first(A, nspec, cnt);
-    }
 
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
@@ -2116,11 +2080,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     Best q;
     best_init<false>(q);
     if constexpr (D >= 4) {      // 4: one pair of rows in flight, 5: two
-        bool same = true;                                        // did the guess hold?  (wave-uniform: LDS broadcast reads)
-#pragma unroll
-        for (int r = 0; r < decltype(P2)::FIRST; r++) same &= nodes[min(r, cnt)] == nspec[min(r, cnt)];
-        if (!same) P2.issue_first(A, nodes, cnt);
-        P2.run(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, stamp);
+        pipe_stream2<T, NCH, D - 3>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, stamp);
     } else if constexpr (D > 0) {
         pipe_stream<T, NCH, D, false>(q, A, B, rows, nodes, (unsigned)(uintptr_t)(lds_u8 *)smem, cnt, 0, 0, stamp);
     } else {
