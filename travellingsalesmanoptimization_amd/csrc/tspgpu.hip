@@ -1846,6 +1846,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // PAY (uint16 cells): the previous launch's result is one atomically minimised key + the
     // winner's geometry record; else: per-workgroup partials, reduced here by every workgroup
     constexpr bool PAY = sizeof(T) == 2;
+    constexpr int PAYW = 16;                            // ints per workgroup record (10 used with f64 edge costs)
     const Partial *part = A.F.partial[rd] + (size_t)t * A.S.pstride;
     Partial pq0;
     pq0.d = 0.0; pq0.key = 0;
@@ -1905,12 +1906,21 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         }
         if (blockIdx.x == 0 && tid == 0) A.F.bestkey[t * 4 + (k_done + 1) % 3] = 0;   // the slot the NEXT launch minimises into
     } else if (k_done > 0) {
+        int gown = tid;                                            // the workgroup whose partial this thread holds
         if (tid < (int)gridDim.x) { md = pq0.d; mkey = pq0.key; }
         for (int g = tid + BT; g < (int)gridDim.x; g += BT) {     // more workgroups than threads: not with the default plans
             const Partial q = part[g];
-            if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; }
+            if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; gown = g; }
         }
+        const double d_own = md;
+        const u64 k_own = mkey;
         block_argmin(md, mkey, scratch);
+        // which workgroup found it (a pair is evaluated once, so its key names one workgroup): that one also left
+        // the geometry record of its pair
+        int *wsel = reinterpret_cast<int *>(scratch + 16);         // 16 ints of slack behind the reduction scratch
+        if (mkey != 0 && k_own == mkey && d_own == md) *wsel = gown;
+        __syncthreads();
+        pwg = __builtin_amdgcn_readfirstlane(*wsel);
     }
     const unsigned long long t_red = stamp ? wall_clock64() : 0ull;
     const bool move = k_done > 0 && md < TWO_OPT_EPS;
@@ -1938,13 +1948,15 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     if (move) {
         int i, j, sma = 0, smb = 0;
         AT cab = 0, css = 0;
-        if constexpr (PAY) {
-            c_i32 *pay = (c_i32 *)(A.F.payload[rd] + ((size_t)t * A.S.pstride + pwg) * 8);
+        {
+            // the winner's record (one scalar load trip): cells of its two nodes, their successors, the two new edge costs
+            c_i32 *pay = (c_i32 *)(A.F.payload[rd] + ((size_t)t * A.S.pstride + pwg) * PAYW);
             const bool sw = pay[2] > pay[4];            // the record is in the winner's orientation (a = its run node)
             i = sw ? pay[1] : pay[0]; j = sw ? pay[0] : pay[1];
             sma = sw ? pay[5] : pay[3]; smb = sw ? pay[3] : pay[5];
-            cab = pay[6]; css = pay[7];
-        } else { i = pos_c[ma]; j = pos_c[mb]; }
+            if constexpr (sizeof(AT) == 8) { cab = *(c_f64 *)(pay + 6); css = *(c_f64 *)(pay + 8); }
+            else { cab = pay[6]; css = pay[7]; }
+        }
         int L = (j - i) * dir_o;
         if (L < 0) L += n;
         const bool other = n - L < L;
@@ -1952,18 +1964,11 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         const int first = other ? wrap(j + dir_o, n) : wrap(i + dir_o, n);
         lo = dir_o > 0 ? first : wrap(first - (M - 1), n);
         if (other) ndir = -dir_o;
-        if constexpr (PAY) {
-            // the four nodes around the reversed range and the two new edge costs follow from the
-            // record: no further memory trip
-            if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
-            else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
-            wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
-        } else {
-            x0 = ord_c[wrap(lo - 1, n)]; x1 = ord_c[lo];
-            x2 = ord_c[wrap(lo + M - 1, n)]; x3 = ord_c[wrap(lo + M, n)];
-            wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
-            wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
-        }
+        // the four nodes around the reversed range and the two new edge costs follow from the
+        // record: no further memory trip (round 1 took three here for int32 / f64 cells: pos, ord, matrix)
+        if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
+        else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
+        wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
     }
     auto new_cell = [&](int p) __attribute__((always_inline)) {   // old cell holding what cell p holds after the move
         int r = p - lo;
@@ -2138,52 +2143,60 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     double d;
     u64 key;
     const bool winner = block_best<T, false>(q, d, key, scratch);
-    if constexpr (PAY) {
-        // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated
-        // once): it leaves the record and takes part in the tour-wide atomic min
-        if (winner) {
-            const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
-            int own = -1, idx = 0;
+    // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated once): it leaves the
+    // geometry record of that pair -- everything it has in registers and LDS anyway -- and, uint16 cells, takes part in
+    // the tour-wide atomic min; other cells: thread 0 leaves the partial the next launch reduces
+    if (winner) {
+        const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
+        int own = -1, idx = 0;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
+        for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
+            const int b0c = (c * BT + tid) * V;
+            if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
+        }
+        if (own < 0) {
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
                 const int b0c = (c * BT + tid) * V;
-                if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
+                if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
             }
-            if (own < 0) {
+        }
+        const int other = own == lb ? la : lb;
+        unsigned pk = 0;
+        int q_old = 0;                        // old array cell of the own node; its new cell follows from the move
 #pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const int b0c = (c * BT + tid) * V;
-                    if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
-                }
-            }
-            const int other = own == lb ? la : lb;
-            unsigned pk = 0;
-            int q_old = 0;                        // old array cell of the own node; its new cell follows from the move
+        for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int c = 0; c < NCH; c++)
-#pragma unroll
-                for (int v = 0; v < V; v++)
-                    if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; q_old = (int)q16[c][v]; }
-            int qr = q_old - lo;
-            if (qr < 0) qr += n;
-            const unsigned qq = (unsigned)(qr < M ? wrap(lo + M - 1 - qr, n) : q_old);
-            const int sb = (int)(pk & 0xffffu) / (int)sizeof(T);
-            int sidx = 0;
-            for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
-            const int sa = nodes[sidx + 1];
-            const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
-            int w1, w2;
-            if constexpr (D == 0) { w1 = (int)rows[(size_t)sidx * ld + own]; w2 = (int)rows[(size_t)(sidx + 1) * ld + sb]; }
-            else { w1 = (int)mat[(size_t)other * ld + own]; w2 = (int)mat[(size_t)sa * ld + sb]; }
-            int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * 8;
-            *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
-            *reinterpret_cast<v4i32 *>(pay + 4) = v4i32{own, sb, w1, w2};
+            for (int v = 0; v < V; v++)
+                if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; if constexpr (PAY) q_old = (int)q16[c][v]; else q_old = qv[c][v]; }
+        int qr = q_old - lo;
+        if (qr < 0) qr += n;
+        const unsigned qq = (unsigned)(qr < M ? wrap(lo + M - 1 - qr, n) : q_old);
+        const int sb = (int)(PAY ? pk & 0xffffu : pk) / (int)sizeof(T);
+        int sidx = 0;
+        for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
+        const int sa = nodes[sidx + 1];
+        const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
+        AT w1, w2;
+        if constexpr (D == 0) { w1 = (AT)rows[(size_t)sidx * ld + own]; w2 = (AT)rows[(size_t)(sidx + 1) * ld + sb]; }
+        else { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
+        int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * PAYW;
+        *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
+        if constexpr (sizeof(AT) == 8) {
+            pay[4] = own; pay[5] = sb;
+            *reinterpret_cast<double *>(pay + 6) = w1;
+            *reinterpret_cast<double *>(pay + 8) = w2;
+        } else *reinterpret_cast<v4i32 *>(pay + 4) = v4i32{own, sb, (int)w1, (int)w2};
+        if constexpr (PAY) {
             const long long K = ((long long)(int)d << 45) | ((long long)la << 29) | ((long long)lb << 13) | (long long)blockIdx.x;
             atomicMin(A.F.bestkey + t * 4 + k_done % 3, K);
         }
-    } else if (tid == 0) {
-        Partial o; o.d = d; o.key = key;
-        A.F.partial[wr][(size_t)t * A.S.pstride + blockIdx.x] = o;
+    }
+    if constexpr (!PAY) {
+        if (tid == 0) {
+            Partial o; o.d = d; o.key = key;
+            A.F.partial[wr][(size_t)t * A.S.pstride + blockIdx.x] = o;
+        }
     }
     STAMP(4);
 #undef STAMP
@@ -3248,7 +3261,7 @@ static int ensure_fused(tspgpu_ctx *ctx)
     }
     HIP_TRY(hipMalloc(&F.cur, T * 4));
     HIP_TRY(hipMalloc(&F.bestkey, T * 4 * 8));
-    for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&F.payload[p], T * (size_t)ctx->S.pstride * 8 * 4));
+    for (int p = 0; p < 2; p++) HIP_TRY(hipMalloc(&F.payload[p], T * (size_t)ctx->S.pstride * 16 * 4));   // 16 ints per workgroup record
     ctx->fcap = ctx->tcap;
     return E_OK;
 }
