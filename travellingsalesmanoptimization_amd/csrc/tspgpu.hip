@@ -1969,6 +1969,12 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
         else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
         wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
+        if constexpr (!PAY && D > 0) {
+            // streamed rows, int32 / f64 cells: the winner no longer has the two matrix cells at hand when it writes its
+            // record (fetching them there puts a memory round trip at the end of EVERY workgroup); one scalar trip here
+            wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
+            wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
+        }
     }
     auto new_cell = [&](int p) __attribute__((always_inline)) {   // old cell holding what cell p holds after the move
         int r = p - lo;
@@ -2177,9 +2183,10 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
         const int sa = nodes[sidx + 1];
         const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
-        AT w1, w2;
+        AT w1 = 0, w2 = 0;
         if constexpr (D == 0) { w1 = (AT)rows[(size_t)sidx * ld + own]; w2 = (AT)rows[(size_t)(sidx + 1) * ld + sb]; }
-        else { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
+        else if constexpr (PAY) { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
+        // (streamed int32 / f64 rows: the reader fetches the two cells itself, see the prologue)
         int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * PAYW;
         *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
         if constexpr (sizeof(AT) == 8) {
