@@ -2152,51 +2152,60 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated once): it leaves the
     // geometry record of that pair -- everything it has in registers and LDS anyway -- and, uint16 cells, takes part in
     // the tour-wide atomic min; other cells: thread 0 leaves the partial the next launch reduces
-    if (winner) {
+    if (key != 0) {                           // (workgroup-uniform: the block's best pair, if it found an improving one)
+        int *xch = reinterpret_cast<int *>(scratch + 16);      // 16 ints of slack behind the reduction scratch
         const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
-        int own = -1, idx = 0;
+        int own = -1, idx = 0, other = 0;
+        if (winner) {
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
-            const int b0c = (c * BT + tid) * V;
-            if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
-        }
-        if (own < 0) {
-#pragma unroll
-            for (int c = 0; c < NCH; c++) {
+            for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
                 const int b0c = (c * BT + tid) * V;
-                if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
+                if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
             }
+            if (own < 0) {
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const int b0c = (c * BT + tid) * V;
+                    if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
+                }
+            }
+            other = own == lb ? la : lb;
+            xch[0] = other;
         }
-        const int other = own == lb ? la : lb;
-        unsigned pk = 0;
-        int q_old = 0;                        // old array cell of the own node; its new cell follows from the move
+        // where in the run the pair's run node sits: one compare per thread instead of a serial walk by the winner
+        __syncthreads();
+        if (tid < cnt && nodes[tid] == xch[0]) xch[1] = tid;
+        __syncthreads();
+        if (winner) {
+            unsigned pk = 0;
+            int q_old = 0;                        // old array cell of the own node; its new cell follows from the move
 #pragma unroll
-        for (int c = 0; c < NCH; c++)
+            for (int c = 0; c < NCH; c++)
 #pragma unroll
-            for (int v = 0; v < V; v++)
-                if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; if constexpr (PAY) q_old = (int)q16[c][v]; else q_old = qv[c][v]; }
-        int qr = q_old - lo;
-        if (qr < 0) qr += n;
-        const unsigned qq = (unsigned)(qr < M ? wrap(lo + M - 1 - qr, n) : q_old);
-        const int sb = (int)(PAY ? pk & 0xffffu : pk) / (int)sizeof(T);
-        int sidx = 0;
-        for (int i = 0; i < cnt; i++) if (nodes[i] == other) sidx = i;
-        const int sa = nodes[sidx + 1];
-        const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
-        AT w1 = 0, w2 = 0;
-        if constexpr (D == 0) { w1 = (AT)rows[(size_t)sidx * ld + own]; w2 = (AT)rows[(size_t)(sidx + 1) * ld + sb]; }
-        else if constexpr (PAY) { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
-        // (streamed int32 / f64 rows: the reader fetches the two cells itself, see the prologue)
-        int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * PAYW;
-        *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
-        if constexpr (sizeof(AT) == 8) {
-            pay[4] = own; pay[5] = sb;
-            *reinterpret_cast<double *>(pay + 6) = w1;
-            *reinterpret_cast<double *>(pay + 8) = w2;
-        } else *reinterpret_cast<v4i32 *>(pay + 4) = v4i32{own, sb, (int)w1, (int)w2};
-        if constexpr (PAY) {
-            const long long K = ((long long)(int)d << 45) | ((long long)la << 29) | ((long long)lb << 13) | (long long)blockIdx.x;
-            atomicMin(A.F.bestkey + t * 4 + k_done % 3, K);
+                for (int v = 0; v < V; v++)
+                    if (c * V + v == idx) { pk = (unsigned)B.sb[c][v]; if constexpr (PAY) q_old = (int)q16[c][v]; else q_old = qv[c][v]; }
+            int qr = q_old - lo;
+            if (qr < 0) qr += n;
+            const unsigned qq = (unsigned)(qr < M ? wrap(lo + M - 1 - qr, n) : q_old);
+            const int sb = (int)(PAY ? pk & 0xffffu : pk) / (int)sizeof(T);
+            const int sidx = xch[1];
+            const int sa = nodes[sidx + 1];
+            const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
+            AT w1 = 0, w2 = 0;
+            if constexpr (D == 0) { w1 = (AT)rows[(size_t)sidx * ld + own]; w2 = (AT)rows[(size_t)(sidx + 1) * ld + sb]; }
+            else if constexpr (PAY) { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
+            // (streamed int32 / f64 rows: the reader fetches the two cells itself, see the prologue)
+            int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * PAYW;
+            *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
+            if constexpr (sizeof(AT) == 8) {
+                pay[4] = own; pay[5] = sb;
+                *reinterpret_cast<double *>(pay + 6) = w1;
+                *reinterpret_cast<double *>(pay + 8) = w2;
+            } else *reinterpret_cast<v4i32 *>(pay + 4) = v4i32{own, sb, (int)w1, (int)w2};
+            if constexpr (PAY) {
+                const long long K = ((long long)(int)d << 45) | ((long long)la << 29) | ((long long)lb << 13) | (long long)blockIdx.x;
+                atomicMin(A.F.bestkey + t * 4 + k_done % 3, K);
+            }
         }
     }
     if constexpr (!PAY) {
