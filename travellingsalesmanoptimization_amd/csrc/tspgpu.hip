@@ -1906,21 +1906,12 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         }
         if (blockIdx.x == 0 && tid == 0) A.F.bestkey[t * 4 + (k_done + 1) % 3] = 0;   // the slot the NEXT launch minimises into
     } else if (k_done > 0) {
-        int gown = tid;                                            // the workgroup whose partial this thread holds
         if (tid < (int)gridDim.x) { md = pq0.d; mkey = pq0.key; }
         for (int g = tid + BT; g < (int)gridDim.x; g += BT) {     // more workgroups than threads: not with the default plans
             const Partial q = part[g];
-            if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; gown = g; }
+            if (key_better(q.d, q.key, md, mkey)) { md = q.d; mkey = q.key; }
         }
-        const double d_own = md;
-        const u64 k_own = mkey;
         block_argmin(md, mkey, scratch);
-        // which workgroup found it (a pair is evaluated once, so its key names one workgroup): that one also left
-        // the geometry record of its pair
-        int *wsel = reinterpret_cast<int *>(scratch + 16);         // 16 ints of slack behind the reduction scratch
-        if (mkey != 0 && k_own == mkey && d_own == md) *wsel = gown;
-        __syncthreads();
-        pwg = __builtin_amdgcn_readfirstlane(*wsel);
     }
     const unsigned long long t_red = stamp ? wall_clock64() : 0ull;
     const bool move = k_done > 0 && md < TWO_OPT_EPS;
@@ -1948,15 +1939,14 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     if (move) {
         int i, j, sma = 0, smb = 0;
         AT cab = 0, css = 0;
-        {
+        if constexpr (PAY) {
             // the winner's record (one scalar load trip): cells of its two nodes, their successors, the two new edge costs
             c_i32 *pay = (c_i32 *)(A.F.payload[rd] + ((size_t)t * A.S.pstride + pwg) * PAYW);
             const bool sw = pay[2] > pay[4];            // the record is in the winner's orientation (a = its run node)
             i = sw ? pay[1] : pay[0]; j = sw ? pay[0] : pay[1];
             sma = sw ? pay[5] : pay[3]; smb = sw ? pay[3] : pay[5];
-            if constexpr (sizeof(AT) == 8) { cab = *(c_f64 *)(pay + 6); css = *(c_f64 *)(pay + 8); }
-            else { cab = pay[6]; css = pay[7]; }
-        }
+            cab = pay[6]; css = pay[7];
+        } else { i = pos_c[ma]; j = pos_c[mb]; }
         int L = (j - i) * dir_o;
         if (L < 0) L += n;
         const bool other = n - L < L;
@@ -1964,14 +1954,20 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         const int first = other ? wrap(j + dir_o, n) : wrap(i + dir_o, n);
         lo = dir_o > 0 ? first : wrap(first - (M - 1), n);
         if (other) ndir = -dir_o;
-        // the four nodes around the reversed range and the two new edge costs follow from the
-        // record: no further memory trip (round 1 took three here for int32 / f64 cells: pos, ord, matrix)
-        if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
-        else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
-        wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
-        if constexpr (!PAY && D > 0) {
-            // streamed rows, int32 / f64 cells: the winner no longer has the two matrix cells at hand when it writes its
-            // record (fetching them there puts a memory round trip at the end of EVERY workgroup); one scalar trip here
+        if constexpr (PAY) {
+            // the four nodes around the reversed range and the two new edge costs follow from the
+            // record: no further memory trip
+            if (!other) { if (dir_o > 0) { x0 = ma; x1 = sma; x2 = mb; x3 = smb; } else { x0 = smb; x1 = mb; x2 = sma; x3 = ma; } }
+            else        { if (dir_o > 0) { x0 = mb; x1 = smb; x2 = ma; x3 = sma; } else { x0 = sma; x1 = ma; x2 = smb; x3 = mb; } }
+            wA = dir_o > 0 ? cab : css; wB = dir_o > 0 ? css : cab;
+        } else {
+            // int32 / f64 cells: three dependent scalar trips (pos, ord, matrix).  A record as above was tried for them
+            // too (round 2): the workgroup that found the pair has to be identified from the partials (an LDS exchange
+            // and a barrier in every workgroup's prologue) and the record costs every workgroup two barriers at its
+            // end -- 31.6 vs 30.9 us (f64), 21.1 vs 20.5 us (int32) per launch at n=4096: the scalar trips are cheap
+            // while nothing else is in flight
+            x0 = ord_c[wrap(lo - 1, n)]; x1 = ord_c[lo];
+            x2 = ord_c[wrap(lo + M - 1, n)]; x3 = ord_c[wrap(lo + M, n)];
             wA = scalar_cell<T>(mat, (size_t)x0 * ld + x2);     // the two new edges {a,b}, {succ a, succ b}
             wB = scalar_cell<T>(mat, (size_t)x1 * ld + x3);
         }
@@ -2149,10 +2145,10 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     double d;
     u64 key;
     const bool winner = block_best<T, false>(q, d, key, scratch);
-    // exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated once): it leaves the
-    // geometry record of that pair -- everything it has in registers and LDS anyway -- and, uint16 cells, takes part in
-    // the tour-wide atomic min; other cells: thread 0 leaves the partial the next launch reduces
-    if (key != 0) {                           // (workgroup-uniform: the block's best pair, if it found an improving one)
+    // uint16 cells: exactly one thread of the workgroup holds the workgroup's best pair (a pair is evaluated once): it
+    // leaves the geometry record of that pair -- everything it has in registers and LDS anyway -- and takes part in the
+    // tour-wide atomic min; other cells: thread 0 leaves the partial the next launch reduces
+    if (PAY && key != 0) {                    // (workgroup-uniform: the block's best pair, if it found an improving one)
         int *xch = reinterpret_cast<int *>(scratch + 16);      // 16 ints of slack behind the reduction scratch
         const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
         int own = -1, idx = 0, other = 0;
@@ -2191,10 +2187,9 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
             const int sidx = xch[1];
             const int sa = nodes[sidx + 1];
             const int cell_a = wrap(p0 + (ndir > 0 ? sidx : cnt - sidx), n);
-            AT w1 = 0, w2 = 0;
+            AT w1, w2;
             if constexpr (D == 0) { w1 = (AT)rows[(size_t)sidx * ld + own]; w2 = (AT)rows[(size_t)(sidx + 1) * ld + sb]; }
-            else if constexpr (PAY) { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
-            // (streamed int32 / f64 rows: the reader fetches the two cells itself, see the prologue)
+            else { w1 = (AT)mat[(size_t)other * ld + own]; w2 = (AT)mat[(size_t)sa * ld + sb]; }
             int *pay = A.F.payload[wr] + ((size_t)t * A.S.pstride + blockIdx.x) * PAYW;
             *reinterpret_cast<v4i32 *>(pay) = v4i32{cell_a, (int)qq, other, sa};
             if constexpr (sizeof(AT) == 8) {
