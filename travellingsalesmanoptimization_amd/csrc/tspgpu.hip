@@ -236,6 +236,59 @@ __device__ __forceinline__ typename Elem<T>::acc cell(const T *mat, const double
     return (AT)edge_weight(pu.x, pu.y, pv.x, pv.y, kind);
 }
 
+// One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
+// correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
+// and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
+// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
+// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
+// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
+constexpr int KIND_CEIL_INT = 3;
+template <int KIND>
+__device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
+{
+    const double dx = bx - ax, dy = by - ay;
+    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
+    if constexpr (KIND == TSPGPU_EUC_2D) {
+        const float x = (float)sq;
+        const float r = __builtin_amdgcn_sqrtf(x);
+        const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
+        const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
+        float c = 0.0f >= em ? rm : r;
+        c = 0.0f < ep ? rp : c;
+        return (int)((double)c + 0.5);
+    } else if constexpr (KIND == KIND_CEIL_INT) {
+        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
+        k = k * k < sq ? k + 1.0 : k;
+        k = k * k < sq ? k + 1.0 : k;
+        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
+        return (int)k;
+    } else return (int)edge_weight(ax, ay, bx, by, KIND);
+}
+
+
+// K1 for the integer storages: the weight kind is a template parameter (no branch per cell) and the integer weight
+// is produced directly (edge_w: for EUC_2D the correctly rounded f32 root written out, see above).  Same cells as
+// k_build_costs<T> below, which stays for f64 storage (weights that may exceed the int range).
+template <typename T, int KIND>
+__global__ void __launch_bounds__(256) k_build_costs_int(const double2 *__restrict__ pts, int n, int ld, T *__restrict__ out)
+{
+    typedef typename Elem<T>::vec VT;
+    constexpr int V = Elem<T>::V;
+    const int i = blockIdx.y;
+    const int j0 = (blockIdx.x * 256 + threadIdx.x) * V;
+    if (j0 >= ld) return;
+    const double2 pi = pts[i];
+    VT o;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        const int j = j0 + k;
+        const double2 pj = pts[min(j, n - 1)];
+        const int w = edge_w<KIND>(pi.x, pi.y, pj.x, pj.y);
+        o[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)w;
+    }
+    *reinterpret_cast<VT *>(out + (size_t)i * ld + j0) = o;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__ pts, int n, int ld, int kind,
                                                      T *__restrict__ out)
@@ -594,36 +647,6 @@ __global__ void __launch_bounds__(1024) k_nn_vec(Tours S, const T *__restrict__ 
         S.status[t] = (step == n) ? 0 : 1; // 1: tour left incomplete
     }
 }
-
-// One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
-// correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
-// and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
-// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
-// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
-// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
-constexpr int KIND_CEIL_INT = 3;
-template <int KIND>
-__device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
-{
-    const double dx = bx - ax, dy = by - ay;
-    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
-    if constexpr (KIND == TSPGPU_EUC_2D) {
-        const float x = (float)sq;
-        const float r = __builtin_amdgcn_sqrtf(x);
-        const float rm = __int_as_float(__float_as_int(r) - 1), rp = __int_as_float(__float_as_int(r) + 1);
-        const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
-        float c = 0.0f >= em ? rm : r;
-        c = 0.0f < ep ? rp : c;
-        return (int)((double)c + 0.5);
-    } else if constexpr (KIND == KIND_CEIL_INT) {
-        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
-        k = k * k < sq ? k + 1.0 : k;
-        k = k * k < sq ? k + 1.0 : k;
-        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
-        return (int)k;
-    } else return (int)edge_weight(ax, ay, bx, by, KIND);
-}
-
 
 // ---------------------------------------------------------------------------
 // K6, third form: nearest-neighbour tour from the COORDINATES through a uniform grid -- for every
@@ -3889,11 +3912,19 @@ int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_
 static int launch_build(tspgpu_ctx *ctx)
 {
     const int n = ctx->n, ld = ctx->ld;
-    ELEM_SWITCH(ctx->elem, T, {
-        constexpr int V = 16 / (int)sizeof(T);
-        dim3 grid((ld / V + 255) / 256, n);
-        hipLaunchKernelGGL((k_build_costs<T>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (T *)ctx->d_mat);
-    });
+    if (ctx->elem == TSPGPU_ELEM_F64) {
+        dim3 grid((ld / 2 + 255) / 256, n);
+        hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (double *)ctx->d_mat);
+    } else {
+        const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+#define BUILD_INT(T, K) hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, n), dim3(256), 0, ctx->stream, \
+                                           ctx->d_pts, n, ld, (T *)ctx->d_mat)
+#define BUILD_KIND(T) do { if (kind == TSPGPU_EUC_2D) BUILD_INT(T, TSPGPU_EUC_2D); else if (kind == TSPGPU_ATT) BUILD_INT(T, TSPGPU_ATT); \
+                           else if (kind == KIND_CEIL_INT) BUILD_INT(T, KIND_CEIL_INT); else BUILD_INT(T, TSPGPU_CEIL_2D); } while (0)
+        if (ctx->elem == TSPGPU_ELEM_I32) BUILD_KIND(int); else BUILD_KIND(u16);
+#undef BUILD_KIND
+#undef BUILD_INT
+    }
     HIP_TRY(hipGetLastError());
     return E_OK;
 }
