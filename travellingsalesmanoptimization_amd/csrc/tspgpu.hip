@@ -266,27 +266,35 @@ __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by
 }
 
 
-// K1 for the integer storages: the weight kind is a template parameter (no branch per cell) and the integer weight
-// is produced directly (edge_w: for EUC_2D the correctly rounded f32 root written out, see above).  Same cells as
-// k_build_costs<T> below, which stays for f64 storage (weights that may exceed the int range).
+// K1 for the integer storages: the weight kind is a template parameter (no branch per cell), the integer weight is
+// produced directly (edge_w: for EUC_2D the correctly rounded f32 root written out, see above), and a workgroup keeps
+// the points of its 256 * V columns in registers while it walks BUILD_ROWS rows -- with one row per workgroup the
+// kernel read 16 bytes of coordinates per 2-byte cell from L2 (268 MB for a 33.5 MB matrix at n=4096) and waited on
+// them 78 % of the time.  Same cells as k_build_costs<T> below, which stays for f64 storage (weights that may exceed
+// the int range; write-bound at 0.70 of the HBM peak as it is).
+constexpr int BUILD_ROWS = 16;
 template <typename T, int KIND>
 __global__ void __launch_bounds__(256) k_build_costs_int(const double2 *__restrict__ pts, int n, int ld, T *__restrict__ out)
 {
     typedef typename Elem<T>::vec VT;
     constexpr int V = Elem<T>::V;
-    const int i = blockIdx.y;
     const int j0 = (blockIdx.x * 256 + threadIdx.x) * V;
     if (j0 >= ld) return;
-    const double2 pi = pts[i];
-    VT o;
+    double2 pj[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) {
-        const int j = j0 + k;
-        const double2 pj = pts[min(j, n - 1)];
-        const int w = edge_w<KIND>(pi.x, pi.y, pj.x, pj.y);
-        o[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)w;
+    for (int k = 0; k < V; k++) pj[k] = pts[min(j0 + k, n - 1)];
+    const int i0 = blockIdx.y * BUILD_ROWS, i1 = min(n, i0 + BUILD_ROWS);
+    for (int i = i0; i < i1; i++) {
+        const double2 pi = pts[i];                       // (wave-uniform: a scalar load)
+        VT o;
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const int j = j0 + k;
+            const int w = edge_w<KIND>(pi.x, pi.y, pj[k].x, pj[k].y);
+            o[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)w;
+        }
+        *reinterpret_cast<VT *>(out + (size_t)i * ld + j0) = o;
     }
-    *reinterpret_cast<VT *>(out + (size_t)i * ld + j0) = o;
 }
 
 template <typename T>
@@ -3917,7 +3925,7 @@ static int launch_build(tspgpu_ctx *ctx)
         hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (double *)ctx->d_mat);
     } else {
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
-#define BUILD_INT(T, K) hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, n), dim3(256), 0, ctx->stream, \
+#define BUILD_INT(T, K) hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, (n + BUILD_ROWS - 1) / BUILD_ROWS), dim3(256), 0, ctx->stream, \
                                            ctx->d_pts, n, ld, (T *)ctx->d_mat)
 #define BUILD_KIND(T) do { if (kind == TSPGPU_EUC_2D) BUILD_INT(T, TSPGPU_EUC_2D); else if (kind == TSPGPU_ATT) BUILD_INT(T, TSPGPU_ATT); \
                            else if (kind == KIND_CEIL_INT) BUILD_INT(T, KIND_CEIL_INT); else BUILD_INT(T, TSPGPU_CEIL_2D); } while (0)
