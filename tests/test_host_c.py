@@ -275,3 +275,32 @@ def test_mod_costs_concurrent_threads(host, O, instances, name):
             assert "%016x" % O.fnv1a(path) == case["fnv"]
         assert host.tsp_gpu_thread_contexts() == 0                   # destroyed at thread exit
     host.tsp_gpu_release()
+
+
+@pytest.mark.parametrize("n", [52, 1002, 85900, 85902])
+def test_vns_kick_matches_the_oracle_at_any_size(host, O, n):
+    """vns_kick (metaheuristic.c:344-409) is host code on the glibc rand() stream: the host layer's kick against the
+    oracle's restatement (itself pinned to the reference's kicks on berlin52 / kroA100 / pr1002) on cycles of config 5's
+    size -- 85 900 nodes, and 85 902, where the reference's out-of-range read tour[n] meets the other malloc padding
+    (4n + 8 a multiple of 16)"""
+    import numpy as np
+    host.tsp_init()
+    host.err_setverbosity(0)
+    inst = Instance.in_dll(host, "tsp_inst")
+    inst.nnodes = n
+    rng = np.random.default_rng(n)
+    perm = rng.permutation(n).astype(np.int32)
+    succ = np.empty(n, dtype=np.int32)
+    succ[perm] = np.roll(perm, -1)                       # one random n-cycle
+    want = succ.copy()
+    O.libc_srand(77)
+    for _ in range(25):
+        O.vns_kick(want)
+    got = succ.copy()
+    host.tsp_srand.argtypes = [C.c_uint]
+    host.tsp_srand(77)
+    host.vns_kick.argtypes = [C.POINTER(Solution)]
+    sol = Solution(0.0, got.ctypes.data_as(C.POINTER(C.c_int)), 0, None)
+    for _ in range(25):
+        assert host.vns_kick(C.byref(sol)) == 0
+    assert np.array_equal(got, want) and O.valid_tour(got)
