@@ -98,6 +98,17 @@ def test_aliased_contexts_shard_like_the_sequential_loop(O, golden, instances, d
         m.close()
 
 
+@pytest.mark.gpu
+def test_multi_rejects_a_device_that_is_not_there():
+    import travellingsalesmanoptimization_amd as T
+    with pytest.raises(T.TspGpuError) as ei:
+        T.MultiEngine([0, 63])
+    assert ei.value.code == 3
+    e = dict(os.environ, TSP_GPU_DEVICES="0, 63")
+    r = subprocess.run([TSP, "-f", data_path("berlin52"), "-alg", "2OPT_GREEDY"], capture_output=True, text=True, timeout=120, env=e, cwd=ROOT)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
 def run_q(*args, env=None):
     e = dict(os.environ)
     e.update(env or {})
