@@ -577,6 +577,42 @@ def test_asymmetric_matrix_strict_orientation(eng, T, O):
     eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
 
 
+@pytest.mark.parametrize("elem,kernel", COMBOS)
+@pytest.mark.parametrize("n,hi", [(97, 60000), (300, 9), (641, 1000000)])
+def test_symmetric_caller_matrices(eng, T, O, n, hi, elem, kernel, fused):
+    """caller matrices that are symmetric but not Euclidean (random integers; many ties with hi = 9; entries beyond
+    uint16 with hi = 1e6): the symmetric shortcuts of the sweeps -- block ownership of a pair, c[a][succ a] read as
+    c[succ a][a], the shorter arc flipped -- against the oracle, every move"""
+    if fused and kernel not in (2, 3):
+        pytest.skip("the fused path exists for the resident and the pipelined kernel")
+    if elem == 3 and hi > 65534:
+        pytest.skip("entries beyond uint16")
+    rng = np.random.default_rng(n + hi)
+    c = rng.integers(1, hi + 1, size=(n, n)).astype(np.float64)
+    c = np.triu(c, 1); c = c + c.T
+    np.fill_diagonal(c, -1.0)
+    c = np.ascontiguousarray(c)
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel)
+    eng.set_costs(c)
+    assert eng.info()["symmetric"] == 1 and eng.info()["nn_grid"] == 0
+    succ, cost = O.nn_tour(c, 0)
+    g, gcost = eng.nn_tour(0)
+    assert gcost == cost and np.array_equal(g, succ)
+    eng.set_option(T.OPT_HISTORY, 4096)
+    want = []
+    while True:
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        if d >= -1e-7:
+            break
+        want.append((min(mv), max(mv), float(d)))
+    got_cost, got_sweeps, rc = eng.two_opt(g)
+    assert rc == 0 and got_sweeps == len(want) + 1 and got_cost == cost and np.array_equal(g, succ)
+    ha, hb, hd = eng.history(len(want))
+    assert [(int(min(a, b)), int(max(a, b)), float(d)) for a, b, d in zip(ha, hb, hd)] == want
+    eng.set_option(T.OPT_HISTORY, 0)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+
+
 def test_float_costs_bit_exact(eng, T, O, instances, golden):
     """the mod-costs regime (heuristics.c:118-149 fed by cplex_model.c:1176-1258): doubles"""
     for case in golden["mod_costs"]:
