@@ -1918,6 +1918,27 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int cnt = min(A.P, n - p0);
     int node_spec = 0;
     if (tid <= cnt + 1) node_spec = ord_o[wrap(p0 + tid - 1, n)];
+    // The workgroup also RECORDS the new state of its slice of nodes (position, both neighbours, both edge costs).  One
+    // node per lane of the second wave, old record loaded here: a single thread doing its eight own nodes was a serial
+    // tail of ~300 instructions in front of the workgroup's barrier.
+    const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // nodes recorded per workgroup
+    const int S0 = BT >= 128 ? 64 : 0;                   // first slice lane
+    int sq = 0, sl_o = 0, sr_o = 0;
+    AT sdl = 0, sdr = 0;
+    auto load_slice = [&](int b) __attribute__((always_inline)) {
+        if constexpr (PAY) {
+            sq = (int)(reinterpret_cast<const u16 *>(A.F.pos[rd]) + tn)[b];
+            const unsigned lr = (reinterpret_cast<const unsigned *>(A.F.nl[rd]) + tn)[b], dd = (reinterpret_cast<const unsigned *>(A.F.dl[rd]) + tn)[b];
+            sl_o = (int)(lr & 0xffffu); sr_o = (int)(lr >> 16);
+            sdl = (AT)(dd & 0xffffu); sdr = (AT)(dd >> 16);
+        } else {
+            sq = pos_o[b]; sl_o = nl_o[b]; sr_o = nr_o[b]; sdl = dl_o[b]; sdr = dr_o[b];
+        }
+    };
+    {
+        const int sl = tid - S0, b = (int)blockIdx.x * slice + sl;
+        if (sl >= 0 && sl < slice && b < n) load_slice(b);
+    }
 
     unsigned long long *stamp = A.stamps ? A.stamps + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 : nullptr;
 #define STAMP(i) do { if (stamp && tid == 0) stamp[i] = wall_clock64(); } while (0)
@@ -2031,7 +2052,6 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     static_assert(HOIST, "the fused kernels are instantiated for NCH * V <= 16 only");
     BState<T, NCH> B;
     B.skm = 0;
-    const int slice = (((n + (int)gridDim.x - 1) / (int)gridDim.x) + V - 1) / V * V;   // b's recorded per workgroup
     const bool fwd = ndir > 0;
     const int wrap_end = lo + M - n;                      // > 0 only when the reversed range wraps round the array end
     const int spA = move ? (fwd ? x0 : x2) : -1, spA_s = fwd ? x2 : x0;    // successor spA_s over an edge of cost wA
@@ -2039,7 +2059,6 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
         const int ub0 = (c * BT + tid) * V;
-        const bool mine = ub0 < n && ub0 / slice == (int)blockIdx.x;
 #pragma unroll
         for (int v = 0; v < V; v++) {
             int q_o, sb;
@@ -2063,41 +2082,32 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
                 if (b >= n) bstate_set<T, NCH>(B, c, v, 0, (AT)0, true, false);
             }
         }
-        if (mine) {
-#pragma unroll
-            for (int v = 0; v < V; v++) {
-                const int b = ub0 + v;
-                int q_o, l_o, r_o;
-                AT dl_v, dr_v;
-                if constexpr (PAY) {
-                    q_o = (int)q16[c][v];
-                    l_o = (int)((unsigned)lv[c][v] & 0xffffu); r_o = (int)((unsigned)lv[c][v] >> 16);
-                    dl_v = (AT)((unsigned)dlv[c][v] & 0xffffu); dr_v = (AT)((unsigned)dlv[c][v] >> 16);
-                } else { q_o = qv[c][v]; l_o = lv[c][v]; r_o = rv[c][v]; dl_v = dlv[c][v]; dr_v = drv[c][v]; }
-                int r = q_o - lo;
-                if (r < 0) r += n;
-                const bool inr = r < M;
-                const int qn = inr ? wrap(lo + M - 1 - r, n) : q_o;
-                int l2 = inr ? r_o : l_o, r2 = inr ? l_o : r_o;
-                AT dl2 = inr ? dr_v : dl_v, dr2 = inr ? dl_v : dr_v;
-                if (move) {
-                    if (b == x0) { r2 = x2; dr2 = wA; }
-                    if (b == x3) { l2 = x1; dl2 = wB; }
-                    if (b == x1) { r2 = x3; dr2 = wB; }
-                    if (b == x2) { l2 = x0; dl2 = wA; }
-                }
-                if (b < n) {
-                    if constexpr (PAY) {
-                        (reinterpret_cast<u16 *>(A.F.pos[wr]) + tn)[b] = (u16)qn;
-                        (reinterpret_cast<unsigned *>(A.F.nl[wr]) + tn)[b] = (unsigned)l2 | ((unsigned)r2 << 16);
-                        (reinterpret_cast<unsigned *>(A.F.dl[wr]) + tn)[b] = (unsigned)dl2 | ((unsigned)dr2 << 16);
-                    } else {
-                        A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
-                        reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
-                        reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
-                    }
-                }
-            }
+    }
+    // the new records of the workgroup's slice of nodes, one node per slice lane
+    for (int sl = tid - S0; sl >= 0 && sl < slice; sl += BT - S0) {
+        const int b = (int)blockIdx.x * slice + sl;
+        if (b >= n) break;
+        if (sl != tid - S0) load_slice(b);               // (a second round: slices longer than the lanes, tiny blocks)
+        int r = sq - lo;
+        if (r < 0) r += n;
+        const bool inr = r < M;
+        const int qn = inr ? wrap(lo + M - 1 - r, n) : sq;
+        int l2 = inr ? sr_o : sl_o, r2 = inr ? sl_o : sr_o;
+        AT dl2 = inr ? sdr : sdl, dr2 = inr ? sdl : sdr;
+        if (move) {
+            if (b == x0) { r2 = x2; dr2 = wA; }
+            if (b == x3) { l2 = x1; dl2 = wB; }
+            if (b == x1) { r2 = x3; dr2 = wB; }
+            if (b == x2) { l2 = x0; dl2 = wA; }
+        }
+        if constexpr (PAY) {
+            (reinterpret_cast<u16 *>(A.F.pos[wr]) + tn)[b] = (u16)qn;
+            (reinterpret_cast<unsigned *>(A.F.nl[wr]) + tn)[b] = (unsigned)l2 | ((unsigned)r2 << 16);
+            (reinterpret_cast<unsigned *>(A.F.dl[wr]) + tn)[b] = (unsigned)dl2 | ((unsigned)dr2 << 16);
+        } else {
+            A.F.pos[wr][tn + b] = qn; A.F.nl[wr][tn + b] = l2; A.F.nr[wr][tn + b] = r2;
+            reinterpret_cast<AT *>(A.F.dl[wr] + tn)[b] = dl2;
+            reinterpret_cast<AT *>(A.F.dr[wr] + tn)[b] = dr2;
         }
     }
     if (blockIdx.x == 0 && tid == 0) {                   // per-tour scalars of the new state
