@@ -449,6 +449,33 @@ def test_n16384_first_sweeps(eng, T, O, fused):
     assert eng.info()["kernel"] == 2
 
 
+def test_full_size_n16384_golden(eng, T, O):
+    """the large size of the throughput table to its local optimum: -n 16384 -seed 123, NN(0) then 2 352 sweeps to 970732
+    (the compiled reference: 2.4 h on one core of the authoring container, tests/golden/golden_n16384_s123.json); both
+    streaming forms of the one-launch-per-sweep kernel"""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_n16384_s123.json")))["two_opt"]
+    xy = O.random_points(16384, 123)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_FUSED, 1)
+    eng.set_points(xy); eng.build_costs()
+    try:
+        for pipe2 in (1, 0):
+            eng.set_option(T.OPT_PIPE2, pipe2)
+            succ, nn_cost = eng.nn_tour(0)
+            assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+            eng.set_option(T.OPT_HISTORY, 32)
+            cost, sweeps, rc = eng.two_opt(succ)
+            assert rc == 0 and (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+            assert eng.info()["pipe2"] == pipe2 and eng.info()["fused"] == 1
+            a, b, d = eng.history(32)
+            run = nn_cost
+            for i, want in enumerate(g["trace"]):
+                run += d[i]
+                assert run == want
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0); eng.set_option(T.OPT_PIPE2, 1)
+
+
 def test_d18512_five_sweeps(eng, T, O, golden):
     """BASELINE config 4's instance: n=18512 (int32 matrix 1.4 GB), NN(0) + 5 sweeps"""
     xy, _ = O.read_tsplib(data_path("d18512"))

@@ -1873,6 +1873,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
     const int k_done = ((c_i32 *)A.F.k[rd])[t];        // sweeps completed before this launch
     const int dir_o = ((c_i32 *)A.F.dir[rd])[t];
     const int stop_o = ((c_i32 *)A.F.stop[rd])[t];
+    const double cost_o = ((c_f64 *)A.F.cost[rd])[t];   // (used by workgroup 0 only; here it costs no dependent trip there)
     const int cap = A.S.cap_sweeps[t];
     // PAY (uint16 cells): the previous launch's result is one atomically minimised key + the
     // winner's geometry record; else: per-workgroup partials, reduced here by every workgroup
@@ -2111,7 +2112,7 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         }
     }
     if (blockIdx.x == 0 && tid == 0) {                   // per-tour scalars of the new state
-        const double cost_n = A.F.cost[rd][t] + (move ? md : 0.0);
+        const double cost_n = cost_o + (move ? md : 0.0);
         A.F.dir[wr][t] = ndir; A.F.k[wr][t] = k_done + (last ? 0 : 1); A.F.cost[wr][t] = cost_n;
         A.F.stop[wr][t] = last ? 1 : 0;
         A.S.nsweeps[t] = k_done + (last ? 0 : 1);
