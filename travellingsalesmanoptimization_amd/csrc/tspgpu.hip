@@ -2174,13 +2174,22 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
 
     // Rows land in chunks of RPC; after each chunk one barrier, then every step whose two rows
     // are in LDS runs while the later rows are still in flight (3 barriers in all for P = 8).
-    constexpr int RPC = TSPGPU_RPC;
+    // (group ends, exclusive: rows [0,3) [3,6) [6,9).  Measured at n=4096 uint16, us per launch: 3,6,9 14.40; 4,7,9
+    // 14.40; 3,5,7,9 14.69; 3,6,8,9 14.73; 2,4,6,8,9 14.85 -- a fourth barrier costs more than the shorter tail after
+    // the last row saves.  -DTSPGPU_RGROUPS=... to compare.)
+#ifndef TSPGPU_RGROUPS
+#define TSPGPU_RGROUPS 3, 6, 9
+#endif
     {
+        constexpr int ends[] = {TSPGPU_RGROUPS};
+        constexpr int NG = (int)(sizeof(ends) / sizeof(ends[0]));
+        static_assert(ends[NG - 1] == PMAX + 1, "the row groups must cover the PMAX + 1 rows of a run");
         int s = 0;
 #pragma unroll
-        for (int r0 = 0; r0 <= PMAX; r0 += RPC) {
+        for (int g = 0; g < NG; g++) {
+            const int r0 = g == 0 ? 0 : ends[g - 1];
 #pragma unroll
-            for (int r = r0; r < r0 + RPC && r <= PMAX; r++) {
+            for (int r = r0; r < ends[g]; r++) {
                 if (r <= cnt && A.ablate != 2) {
                     VT *dst = reinterpret_cast<VT *>(rows + (size_t)r * ld);
 #pragma unroll
@@ -2188,8 +2197,8 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
                 }
             }
             __syncthreads();
-            if (r0 == 0) STAMP(2);
-            const int s_end = min(cnt, r0 + RPC - 1);   // steps s with row s+1 <= r0+RPC-1
+            if (g == 0) STAMP(2);
+            const int s_end = min(cnt, ends[g] - 1);   // steps s with row s+1 < ends[g]
             for (; s < s_end; s++) step(s);
         }
     }
