@@ -63,8 +63,12 @@ enum {
                                    interval where four rows fit LDS, 0 one edge per barrier over three row buffers */
     TSPGPU_OPT_NN_KERNEL = 14,  /* nearest-neighbour construction: 0 auto (the grid kernel whenever the weights come from
                                    the uploaded points, else the matrix kernel), 1 matrix / strided kernels always */
-    TSPGPU_OPT_SWEEP_CAP = 13   /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
+    TSPGPU_OPT_SWEEP_CAP = 13,  /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
                                    reference's behaviour; >= 0 caps every local search: tests and bounded runs) */
+    TSPGPU_OPT_PERSIST = 16,    /* single-tour descent with the whole uint16 matrix resident in LDS, one launch per descent
+                                   (n <= 4096, one workgroup per CU): 0 never, 1 (default) where it applies -- falls back to
+                                   one launch per sweep when the grid cannot be co-resident --, 2 or fail with code 8 */
+    TSPGPU_OPT_PERSIST_EDGES = 17 /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16) */
 };
 
 int  tspgpu_device_count(void);
@@ -77,7 +81,7 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup,
  * 10 matrix-free mode in use, 11 one-launch-per-sweep path in use, 12 cells per side of the NN grid (0: the
  * grid kernel is not in use), 13 most points in one grid cell, 14 the fused streaming kernel takes two edges per
- * barrier interval */
+ * barrier interval, 15 the last single-tour descent ran LDS-resident (TSPGPU_OPT_PERSIST) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

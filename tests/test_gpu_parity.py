@@ -973,3 +973,119 @@ def test_pla85900_config5(eng, T, O):
         assert (int(a[i]), int(b[i]), float(d[i])) == (m["a"], m["b"], m["delta"])
     assert cost == g["moves"][-1]["cost"] and fx(O, succ) == g["moves"][-1]["fnv"]
     assert O.valid_tour(succ)
+
+
+# ------------------------------------------------------------------ the LDS-resident descent (k_lds2opt)
+@pytest.fixture
+def persist(eng, T):
+    """TSPGPU_OPT_PERSIST = 2: the single-tour descent must run in k_lds2opt (or fail loudly)"""
+    eng.set_option(T.OPT_PERSIST, 2)
+    yield
+    eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_EDGES, 0)
+
+
+@pytest.mark.parametrize("edges", [0, 3, 16])
+@pytest.mark.parametrize("name", ["kroA100", "n64_s7", "n200_s3", "pr1002", "n1000_s123"])
+def test_lds_resident_trajectory(eng, T, O, instances, name, edges, persist):
+    """every sweep of the LDS-resident kernel picks the reference's (a, b) and leaves the reference's tour: packed
+    16-bit deltas (costs <= 16383) and the 32-bit form (pr1002), n % 8 != 0 (kroA100, pr1002), 1 .. 16 edges per workgroup"""
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST_EDGES, edges)
+    succ, cost = O.nn_tour(c, 0)
+    g = succ.copy(); gcost = cost
+    for _ in range(60):
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        gd, gcost = eng.two_opt_once(g, gcost)
+        assert eng.info()["persist"] == 1
+        assert gd == d and gcost == cost and np.array_equal(g, succ), (mv, d, gd)
+        if d >= -1e-7:
+            break
+
+
+@pytest.mark.parametrize("edges", [0, 7])
+@pytest.mark.parametrize("name", ["kroA100", "pr1002", "n1000_s123", "n1024_s1", "n200_s3", "n4096_s123"])
+def test_lds_resident_to_local_optimum_golden(eng, T, O, instances, golden, name, edges, persist):
+    """one launch for the whole descent: golden sweep count, final cost, tour and the per-sweep cost trace the
+    reference printed -- including BASELINE's headline configuration (n=4096: 609 sweeps to 488522)"""
+    if name == "n4096_s123":
+        xy = O.random_points(4096, 123); c = None
+        eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+        eng.set_points(xy); eng.build_costs()
+        if edges:
+            pytest.skip("n=4096 fills the LDS with 16 edges per workgroup")
+    else:
+        xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST_EDGES, edges)
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    succ, nn_cost = eng.nn_tour(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    eng.set_option(T.OPT_HISTORY, 4096)
+    try:
+        cost, sweeps, rc = eng.two_opt(succ)
+        assert rc == 0 and eng.info()["persist"] == 1
+        assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+        assert O.valid_tour(succ)
+        if c is not None:
+            assert O.tour_cost(c, succ) == cost
+        a, b, d = eng.history(4096)
+        assert len(a) == sweeps and a[-1] == -1
+        run = nn_cost
+        for i, want in enumerate(g["trace"]):
+            run += d[i]
+            assert run == want
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0)
+
+
+def test_lds_resident_sweep_cap_and_deadline(eng, T, O, instances, golden, persist):
+    """a sweep cap stops after exactly that many applied moves (same state as the reference after as many calls of
+    ref_2opt_once); a deadline returns code 4 with a consistent tour: valid, its cost the tour's cost, the sweep count
+    the recorded history's length; no time left = not one sweep"""
+    xy, c = setup(eng, T, O, instances, "n1000_s123", 3, 0)
+    succ, cost = O.nn_tour(c, 0)
+    eng.tour_load(0, succ)
+    sw, rc = eng.tour_two_opt(0, max_sweeps=25)
+    assert (sw, rc) == (25, 0) and eng.info()["persist"] == 1
+    for _ in range(25):
+        d, cost, _ = O.two_opt_once(c, succ, cost)
+    got, gcost, _ = eng.tour_store(0)
+    assert gcost == cost and np.array_equal(got, succ)
+    # deadline
+    succ0, cost0 = O.nn_tour(c, 0)
+    eng.set_option(T.OPT_HISTORY, 4096)
+    try:
+        g = succ0.copy()
+        gcost, sweeps, rc = eng.two_opt(g, time_left_s=0.0003)
+        a, b, d = eng.history(4096)
+        assert rc == 4 and 0 < sweeps < golden["random"]["n1000_s123"]["two_opt"]["sweeps"]
+        assert O.valid_tour(g) and O.tour_cost(c, g) == gcost and len(a) == sweeps and cost0 + d.sum() == gcost
+        g = succ0.copy()
+        gcost, sweeps, rc = eng.two_opt(g, time_left_s=0.0)
+        assert rc == 4 and sweeps == 0 and np.array_equal(g, succ0)
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0)
+
+
+def test_lds_resident_caller_matrix(eng, T, O, instances, persist):
+    """a caller-supplied symmetric integer matrix (not Euclidean: random weights, triangle inequality violated, many
+    ties) through tspgpu_set_costs: the kernel's tie order and its poisoned diagonal against the oracle"""
+    r = np.random.RandomState(11)
+    n = 333
+    m = r.randint(1, 40, size=(n, n)).astype(np.float64)
+    m = np.triu(m, 1); m = m + m.T
+    np.fill_diagonal(m, -1.0)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_costs(m)
+    c = m.copy()
+    succ = np.roll(np.arange(n, dtype=np.int32), -1)
+    perm = r.permutation(n).astype(np.int32)
+    succ = np.empty(n, dtype=np.int32); succ[perm] = np.roll(perm, -1)
+    cost = O.tour_cost(c, succ)
+    g = succ.copy(); gcost = cost
+    for _ in range(80):
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        gd, gcost = eng.two_opt_once(g, gcost)
+        assert eng.info()["persist"] == 1
+        assert gd == d and gcost == cost and np.array_equal(g, succ), (mv, d, gd)
+        if d >= -1e-7:
+            break

@@ -337,6 +337,7 @@ __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, i
     if (!(r == x && x >= -1.0 && x < 134217728.0)) flags[0] = 1;
     if (j > i && m[(size_t)j * ld + i] != x) flags[1] = 1;
     if (i == j ? x != -1.0 : !(r == x && x >= 0.0 && x <= 65534.0)) flags[2] = 1;
+    if (i != j && !(x <= 16383.0)) flags[3] = 1;
 }
 
 template <typename TD>
@@ -2739,6 +2740,8 @@ __global__ void k_cap_now(Tours S, int slot0, int count)
     if (i < count && !S.done[slot0 + i]) S.cap_sweeps[slot0 + i] = S.nsweeps[slot0 + i];
 }
 
+#include "tspgpu_lds2opt.inc"
+
 // ===========================================================================
 // host side
 // ===========================================================================
@@ -2800,6 +2803,15 @@ struct tspgpu_ctx {
     bool plan_pipe2 = false;    // the fused pipelined kernel streams two tour edges per barrier interval (pipe_stream2)
     bool plan_pipe2_sweep = false;   // ... and so does the plain pipelined sweep (batches; symmetric, not tabu)
     int opt_pipe2 = 1;          // 1 = use that form where four rows fit LDS, 0 = never
+
+    // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
+    int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
+    int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
+    u64 *d_lp_slots = nullptr; int *d_lp_ctl = nullptr; int *h_lp = nullptr;
+    bool lp_broken = false;    // the grid did not come up co-resident once: keep to the one-launch-per-sweep path
+    bool lp_used = false;      // the last descent ran in k_lds2opt
+    bool lp_attr[2] = {false, false};
+    bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
 
     Fused F{};                 // fused path state (allocated on first use, capacity fcap)
     int fcap = 0;
@@ -3511,6 +3523,96 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
     return E_OK;
 }
 
+// The LDS-resident descent (k_lds2opt) where it applies: uint16 cells, one tour, a whole chip whose LDS holds the matrix.
+static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds)
+{
+    const int n = ctx->n;
+    if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 64 || n > 4096) return false;
+    int e = (n + ctx->cus - 1) / ctx->cus;
+    if (ctx->opt_persist_edges > e) e = ctx->opt_persist_edges;
+    if (e > LP_EMAX || e > n / 4) return false;
+    const size_t nl = (size_t)((n + 7) & ~7);
+    lds = (size_t)(e + 1) * nl * 2 + nl * 4 + std::max<size_t>(nl * 2, 256);
+    if (lds > ctx->lds_max) return false;
+    E = e; W = (n + e - 1) / e;
+    return W <= ctx->cus && W <= LP_BT;
+}
+
+// *ran = false: nothing was touched (does not apply, or the grid did not come up co-resident): the caller takes the
+// one-launch-per-sweep path.  Deadline: launches with a sweep budget of a third of the time left, measured per sweep;
+// every launch leaves a consistent tour (the sweep that ran is applied, refinment.c:17-26).
+static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *deadline_hit, bool *ran)
+{
+    *ran = false;
+    int E = 0, W = 0;
+    size_t lds = 0;
+    if (ctx->lp_broken || !persist_fits(ctx, E, W, lds)) return E_OK;
+    if (!ctx->d_lp_slots) {
+        HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64));
+        HIP_TRY(hipMalloc(&ctx->d_lp_ctl, 64));
+        HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
+    }
+    const int pk = ctx->max16k ? 1 : 0;
+    const void *fn = pk ? (const void *)k_lds2opt<true> : (const void *)k_lds2opt<false>;
+    if (!ctx->lp_attr[pk]) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
+        ctx->lp_attr[pk] = true;
+    }
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; *ran = true; ctx->lp_used = true; return E_OK; }
+    double sweep_s = 8e-6;
+    bool first = true, late = false;
+    int retries = 0;
+    for (;;) {
+        int budget = -1;
+        if (t_end >= 0) {
+            const double left = t_end - now_s();
+            if (left <= 0) { late = true; break; }
+            budget = (int)std::min(1048576.0, std::max(1.0, left / 3.0 / sweep_s));
+        }
+        HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_lp_ctl, 0, 64, ctx->stream));
+        PersistArgs A;
+        memset(&A, 0, sizeof A);
+        A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
+        A.E = E; A.nl = (ctx->n + 7) & ~7; A.budget = budget;
+        A.slots = ctx->d_lp_slots; A.ctl = ctx->d_lp_ctl; A.hist = ctx->hist;
+        A.hello_ticks = 200000;        // 2 ms
+        A.spin_ticks = 100000000;      // 1 s
+        A.stamps = nullptr;
+        void *args[] = {&A};
+        const double t0 = now_s();
+        if (ctx->opt_timing) {
+            while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        }
+        HIP_TRY(hipLaunchKernel(fn, dim3(W), dim3(LP_BT), args, lds, ctx->stream));
+        if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_lp, ctx->d_lp_ctl, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
+        if (status == LP_ST_NO_RENDEZVOUS) {
+            if (first) { ctx->lp_broken = true; return E_OK; }       // nothing written: the other path takes over
+            if (++retries > 3) return fail(ctx, E_INTERNAL, "LDS-resident descent: the grid of %d workgroups did not come up co-resident", W);
+            continue;
+        }
+        if (status == LP_ST_LOST || status == LP_ST_RUNNING)
+            return fail(ctx, E_INTERNAL, "LDS-resident descent: exchange lost (status %d after %d sweeps)", status, sd);
+        first = false;
+        if (ctx->opt_timing && sd > 0) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->sweep_ms_total += ms; ctx->sweep_launches += sd;
+        }
+        if (sd > 0) sweep_s = (now_s() - t0) / sd;
+        if (status == LP_ST_OPTIMUM || status == LP_ST_CAPPED) break;
+    }
+    if (late && deadline_hit) *deadline_hit = true;
+    *ran = true;
+    ctx->lp_used = true;
+    return E_OK;
+}
+
 // Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
 // done, `max_iters` pairs were issued (tabu), or the deadline passed (checked before every batch; the batches
 // shrink to single iterations once fewer than three batches' worth of time is left, refinment.c:17-24).
@@ -3526,6 +3628,15 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
     // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
     // tour at once and the leaner sweep wins (measured 7.0e11 vs 5.0e11 evals/s at 64 tours).
+    ctx->lp_used = false;
+    // (an explicit kernel or launch-structure choice -- TSPGPU_OPT_KERNEL / _FUSED -- keeps to that choice)
+    if (!tabu && ntours == 1 && (ctx->opt_persist == 2 || (ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1))) {
+        bool ran = false;
+        const int rc = run_persist(ctx, slot0, time_left_s, deadline_hit, &ran);
+        if (rc) return rc;
+        if (ran) return E_OK;
+        if (ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident descent does not apply (uint16 cells, n in [64, 4096], one idle chip)");
+    }
     if (!tabu && ctx->symmetric && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2) &&
         (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
         return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
@@ -3848,6 +3959,9 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     free_tours(ctx);
     if (ctx->d_pts) hipFree(ctx->d_pts);
     if (ctx->d_flags) hipFree(ctx->d_flags);
+    if (ctx->d_lp_slots) hipFree(ctx->d_lp_slots);
+    if (ctx->d_lp_ctl) hipFree(ctx->d_lp_ctl);
+    if (ctx->h_lp) hipHostFree(ctx->h_lp);
     if (ctx->d_trace) hipFree(ctx->d_trace);
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->d_spts) hipFree(ctx->d_spts);
@@ -3894,6 +4008,8 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
+    case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_broken = false; break;
+    case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LP_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LP_EMAX); ctx->opt_persist_edges = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
     case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
     case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
@@ -3919,6 +4035,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 10: return ctx->otf ? 1 : 0;
     case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2)) ? 1 : 0;
     case 14: return (ctx->plan_pipe2 || ctx->plan_pipe2_sweep) ? 1 : 0;
+    case 15: return ctx->lp_used ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
@@ -4003,6 +4120,7 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
     int rc = launch_build(ctx);
     if (rc) return rc;
     ctx->symmetric = true; // Euclidean
+    ctx->max16k = ctx->cost_bound <= 16383.0;
     ctx->have_costs = true;
     ctx->built = true;
     ctx->plan_kernel = 0;
@@ -4032,10 +4150,11 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
     HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->stream));
     hipLaunchKernelGGL(k_inspect, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, stage, n, ld, ctx->d_flags);
     HIP_TRY(hipGetLastError());
-    int flags[3] = {0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 12, hipMemcpyDeviceToHost, ctx->stream));
+    int flags[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const bool integral = flags[0] == 0, fits16 = flags[2] == 0;
+    ctx->max16k = fits16 && flags[3] == 0;
     ctx->symmetric = flags[1] == 0;
     if ((ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) || (ctx->opt_elem == TSPGPU_ELEM_U16 && !fits16)) {
         hipFree(stage);
