@@ -3579,7 +3579,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         A.slots = ctx->d_lp_slots; A.ctl = ctx->d_lp_ctl; A.hist = ctx->hist;
         A.hello_ticks = 200000;        // 2 ms
         A.spin_ticks = 100000000;      // 1 s
-        A.stamps = nullptr;
+        A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
         void *args[] = {&A};
         const double t0 = now_s();
         if (ctx->opt_timing) {
