@@ -39,12 +39,23 @@ for n in ns[:1]:
     buf = np.zeros(1024 * 64, dtype=np.uint64)
     eng.L.tspgpu_debug_stamps(eng.ctx, buf.ctypes.data, buf.size)
     eng.set_option(98, 0)
-    st = buf.reshape(-1, 16)[:256, :9].astype(np.float64)
+    st = buf.reshape(-1, 16)[:256, :13].astype(np.float64)
     st = st[st[:, 8] > 0]
     names = ["evaluation", "reduction", "exchange", "reversal", "rows fetched", "decode+swaps"]
     print(f"n={n}: {len(st)} workgroups, {int(st[0, 8])} sweeps; per sweep (us), mean / min / max over workgroups:")
     for i, nm in enumerate(names):
         v = st[:, i] / st[:, 8] / 100.0
         print(f"  {nm:14s} {v.mean():7.3f} {v.min():7.3f} {v.max():7.3f}")
+    for i, nm in enumerate(["  decode", "  need/mirror", "  row swaps"]):
+        v = st[:, 9 + i] / st[:, 8] / 100.0
+        print(f"  {nm:14s} {v.mean():7.3f} {v.min():7.3f} {v.max():7.3f}")
+    log = buf[8192 + 1:8192 + 1 + int(st[0, 8]) - 1]
+    tt = (log & np.uint64(0xFFFFFFFFFFFF)).astype(np.float64) / 100.0
+    mm = (log >> np.uint64(48)).astype(np.int64)
+    dt = np.diff(tt); mcur = mm[1:]; mprev = mm[:-1]      # sweep s lasts from the end of the move of s-1 to the end of its own move
+    for lo_, hi_ in ((2, 8), (8, 16), (16, 64), (64, 256), (256, 1024), (1024, 4096)):
+        sel = (mcur >= lo_) & (mcur < hi_)
+        if sel.any():
+            print(f"  sweeps reversing {lo_:4d} <= M < {hi_:4d}: {sel.sum():4d}, mean {dt[sel].mean():6.2f} us (min {dt[sel].min():5.2f}, max {dt[sel].max():5.2f})")
     print(f"  sweeps with a fetch per workgroup: mean {st[:, 6].mean():.1f} max {st[:, 6].max():.0f}; rows fetched per workgroup: mean {st[:, 7].mean():.0f}")
 eng.close()
