@@ -248,6 +248,9 @@ def main():
     CTYPE = {T.ELEM_U16: "unsigned short", T.ELEM_I32: "int", T.ELEM_F64: "double"}
 
     def kernel_name(info):
+        if info.get("persist"):
+            return ("k_lds2opt (uint16 matrix resident in LDS in tour order, ONE launch per descent; "
+                    "kernel_ms_mean = launch duration / sweeps of the launch)")
         if info.get("fused"):
             return "k_sweep_fused (sweep + apply of the previous move, one launch per sweep)"
         return {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res", 4: "k_sweep_otf"}[info["kernel"]]
@@ -265,12 +268,24 @@ def main():
         bpe = 2 * BYTES[info["elem"]]                     # 2 matrix elements per eval
         kernel_ms = ms_total / max(launches, 1)
         achieved = evals * bpe / (kernel_ms * 1e-3) / 1e9
-        return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,    # PMC counters need their own rocprofv3 pass; the committed pass is quoted beside it
-                "traffic_from_committed_profile": load_traffic(f"n{info['n']}_{NAMES[info['elem']]}" + ("_fused" if info.get("fused") else "")),
-                "kernel": kernel_name(info), "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
-                "algorithmic_bytes_per_launch": evals * bpe, "bytes_per_eval": bpe, "evals_per_launch": evals,
-                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
+        suffix = "_persist" if info.get("persist") else "_fused" if info.get("fused") else ""
+        out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": None,    # PMC counters need their own rocprofv3 pass; the committed pass is quoted beside it
+               "traffic_from_committed_profile": load_traffic(f"n{info['n']}_{NAMES[info['elem']]}" + suffix),
+               "kernel": kernel_name(info), "kernel_ms_mean": kernel_ms, "kernel_launches_timed": launches,
+               "algorithmic_bytes_per_launch": evals * bpe, "bytes_per_eval": bpe, "evals_per_launch": evals,
+               "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
+        if info.get("persist"):
+            # one launch runs the whole descent: the unit of the roofline is one SWEEP (= the work of one launch of the
+            # per-sweep kernels: n(n-3)/2 evaluations, 2 matrix cells each).  The cells come from LDS, not HBM: the
+            # fraction is the SURVEY 8d convention (algorithmic bytes / time / HBM peak), not a measure of HBM traffic.
+            out["unit_of_work"] = "sweep (launch duration / sweeps run by the launch)"
+            out["kernel_launches_timed"] = 1
+            out["sweeps_timed"] = launches
+            out["note"] = ("matrix cells are read from LDS (33.5 MB of the chip's 41.9 MB), HBM traffic per sweep is the rows "
+                           "re-fetched after a move (see traffic_from_committed_profile); bound in practice: the grid-wide "
+                           "exchange per sweep (DESIGN.md 4.7)")
+        return out
 
     def build_roofline(eng):
         """K1: one launch stores sizeof(cell) * n * ld bytes (write-bound)"""
@@ -385,14 +400,28 @@ def main():
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         tmax, tot_sweeps = float(t.item()), int(s.item())
 
+    info_main = eng.info()                 # (the path the timed steps took)
     gate = parity(n, seed, my_sweeps // max(args.steps, 1), final_cost, path) if rank == 0 and start == 0 else None
     if gate and gate.get("golden") and not gate["ok"]:
         raise SystemExit(f"parity gate failed: {gate}")        # a fast kernel whose result differs is not a result
 
-    roof = None
+    roof = roof_fused = None
     if rank == 0:
         roof = timed_search(eng, evals)
         roof["kernel_ms_back_to_back"] = eng.time_sweep(1, 50)   # the sweep part alone (no move applied between launches)
+        if eng.info().get("persist"):
+            # the one-launch-per-sweep kernel on the same workload (what runs for f64 / int32 cells, n > 4096, batches)
+            eng.set_option(T.OPT_PERSIST, 0)
+            try:
+                t1 = time.perf_counter()
+                sw1 = step()
+                torch.cuda.synchronize()
+                dt1 = time.perf_counter() - t1
+                roof_fused = timed_search(eng, evals)
+                roof_fused["ms_per_step"] = 1e3 * dt1
+                roof_fused["value"] = sw1 * evals / dt1
+            finally:
+                eng.set_option(T.OPT_PERSIST, 1)
 
     base = None
     if aux and args.cpu_sweeps > 0:
@@ -555,12 +584,15 @@ def main():
                    "matrix_elem": {T.ELEM_U16: "uint16 exact copy", T.ELEM_I32: "int32 exact copy", T.ELEM_F64: "f64"}[info["elem"]],
                    "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
                    "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
+                   "descent": ({"kernel": "k_lds2opt", "launches_per_descent": 1, "workgroups": info_main["persist_wgs"],
+                                "edges_per_workgroup": info_main["persist_edges"], "lds_bytes": info_main["persist_lds"], "block": 512}
+                               if info_main.get("persist") else {"kernel": "one launch per sweep"}),
                    "parallelism": f"multistart-shard{world}"},
         "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,
         "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost, "parity": gate,
         "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
-        "roofline": roof, "roofline_build": broof, "cpu_baseline": base, "other_matrix_storage": other,
-        "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
+        "roofline": roof, "roofline_one_launch_per_sweep": roof_fused, "roofline_build": broof, "cpu_baseline": base,
+        "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
     }
     if base and "value" in base:
         out["gpu_over_cpu"] = out["value"] / base["value"]

@@ -81,7 +81,8 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * 7 matrix is symmetric, 8 compute units, 9 rows in flight per workgroup,
  * 10 matrix-free mode in use, 11 one-launch-per-sweep path in use, 12 cells per side of the NN grid (0: the
  * grid kernel is not in use), 13 most points in one grid cell, 14 the fused streaming kernel takes two edges per
- * barrier interval, 15 the last single-tour descent ran LDS-resident (TSPGPU_OPT_PERSIST) */
+ * barrier interval, 15 the last single-tour descent ran LDS-resident (TSPGPU_OPT_PERSIST), 16 / 17 / 18 workgroups, tour
+ * edges per workgroup and LDS bytes per workgroup of that kernel on this instance (0: it does not apply) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

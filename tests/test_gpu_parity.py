@@ -1089,3 +1089,37 @@ def test_lds_resident_caller_matrix(eng, T, O, instances, persist):
         assert gd == d and gcost == cost and np.array_equal(g, succ), (mv, d, gd)
         if d >= -1e-7:
             break
+
+
+def test_lds_resident_two_contexts_one_gpu(T, O, golden):
+    """two contexts on one GPU descend at the same time (two host threads): k_lds2opt needs the whole chip, so the
+    two grids may come up interleaved -- the rendezvous then fails within its time limit, nothing has been touched and
+    the descent runs one launch per sweep instead.  Whichever path ran: the golden result, no hang."""
+    import threading
+    g = golden["random"]["n4096_s123"]["two_opt"]
+    xy = O.random_points(4096, 123)
+    engines = [T.Engine(0) for _ in range(2)]
+    out = [None, None]
+
+    def work(i):
+        e = engines[i]
+        e.set_option(T.OPT_ELEM, 3)
+        e.set_points(xy); e.build_costs()
+        res = []
+        for _ in range(3):
+            succ, _ = e.nn_tour(0)
+            cost, sweeps, rc = e.two_opt(succ)
+            res.append((rc, sweeps, cost, fx(O, succ), e.info()["persist"]))
+        out[i] = res
+
+    try:
+        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in th: t.start()
+        for t in th: t.join(timeout=300)
+        assert not any(t.is_alive() for t in th)
+        for res in out:
+            assert res is not None
+            for rc, sweeps, cost, h, used in res:
+                assert (rc, sweeps, cost, h) == (0, g["sweeps"], g["final_cost"], g["final_fnv"]), (res, out)
+    finally:
+        for e in engines: e.close()

@@ -211,6 +211,11 @@ def test_bench_line_contract():
         assert k in d
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    # the headline descent runs LDS-resident (one launch); the per-sweep kernel is reported beside it
+    assert d["config"]["descent"]["kernel"] == "k_lds2opt" and d["config"]["descent"]["workgroups"] == 256
+    assert r["kernel"].startswith("k_lds2opt") and r["sweeps_timed"] == 609 and r["kernel_launches_timed"] == 1
+    f = d["roofline_one_launch_per_sweep"]
+    assert f["kernel"].startswith("k_sweep_fused") and f["kernel_launches_timed"] >= 576 and f["kernel_ms_mean"] > r["kernel_ms_mean"]
 
 
 def _mod_costs_matrix(c, seed):

@@ -4036,6 +4036,11 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2)) ? 1 : 0;
     case 14: return (ctx->plan_pipe2 || ctx->plan_pipe2_sweep) ? 1 : 0;
     case 15: return ctx->lp_used ? 1 : 0;
+    case 16: case 17: case 18: {             // geometry of the LDS-resident descent (0: it does not apply to the instance)
+        int E = 0, W = 0; size_t lds = 0;
+        if (!persist_fits(ctx, E, W, lds)) return 0;
+        return what == 16 ? W : what == 17 ? E : (long)lds;
+    }
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
