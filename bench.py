@@ -209,6 +209,8 @@ def main():
     ap.add_argument("--elem", choices=["auto", "u16", "i32", "f64"], default=os.environ.get("TSPGPU_BENCH_ELEM", "auto"),
                     help="matrix storage; auto = the engine's default (narrowest exact copy)")
     ap.add_argument("--kernel", type=int, default=0)
+    ap.add_argument("--persist", type=int, default=1, choices=[0, 1, 2],
+                    help="TSPGPU_OPT_PERSIST: 1 = the LDS-resident descent where it applies (default), 0 = one launch per sweep")
     ap.add_argument("--wgs", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--batch", type=int, default=32)
@@ -353,6 +355,7 @@ def main():
     eng.set_option(T.OPT_WGS_PER_TOUR, args.wgs)
     eng.set_option(T.OPT_BLOCK, args.block)
     eng.set_option(T.OPT_BATCH, args.batch)
+    eng.set_option(T.OPT_PERSIST, args.persist)
 
     # ---- untimed setup: instance, matrix build on the device, NN seed tour in slot 0
     xy = reference_points(n, seed)
@@ -421,7 +424,7 @@ def main():
                 roof_fused["ms_per_step"] = 1e3 * dt1
                 roof_fused["value"] = sw1 * evals / dt1
             finally:
-                eng.set_option(T.OPT_PERSIST, 1)
+                eng.set_option(T.OPT_PERSIST, args.persist)
 
     base = None
     if aux and args.cpu_sweeps > 0:
