@@ -1123,3 +1123,27 @@ def test_lds_resident_two_contexts_one_gpu(T, O, golden):
                 assert (rc, sweeps, cost, h) == (0, g["sweeps"], g["final_cost"], g["final_fnv"]), (res, out)
     finally:
         for e in engines: e.close()
+
+
+def test_lds_resident_rendezvous_failure_falls_back(T, O, instances, golden):
+    """the grid of k_lds2opt does not come up as a whole (test hook 97: workgroup 0 withholds its record): every
+    workgroup leaves within the limit, the tour is untouched, the descent runs one launch per sweep -- this call and
+    the next ones of the context -- to the golden result; asking for the LDS-resident kernel explicitly re-arms it"""
+    e = T.Engine(0)
+    try:
+        xy, c = instances("n1000_s123")
+        g = golden["random"]["n1000_s123"]["two_opt"]
+        e.set_option(T.OPT_ELEM, 3); e.set_points(xy); e.build_costs()
+        e.set_option(97, -50000)                     # 0.5 ms
+        for _ in range(2):
+            succ, _ = e.nn_tour(0)
+            cost, sweeps, rc = e.two_opt(succ)
+            assert rc == 0 and e.info()["persist"] == 0
+            assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+        e.set_option(97, 0); e.set_option(T.OPT_PERSIST, 1)
+        succ, _ = e.nn_tour(0)
+        cost, sweeps, rc = e.two_opt(succ)
+        assert rc == 0 and e.info()["persist"] == 1
+        assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+    finally:
+        e.close()

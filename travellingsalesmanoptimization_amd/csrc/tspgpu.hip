@@ -2807,6 +2807,7 @@ struct tspgpu_ctx {
     // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
     int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
+    long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     u64 *d_lp_slots = nullptr; int *d_lp_ctl = nullptr; int *h_lp = nullptr;
     bool lp_broken = false;    // the grid did not come up co-resident once: keep to the one-launch-per-sweep path
     bool lp_used = false;      // the last descent ran in k_lds2opt
@@ -3577,7 +3578,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
         A.E = E; A.nl = (ctx->n + 7) & ~7; A.budget = budget;
         A.slots = ctx->d_lp_slots; A.ctl = ctx->d_lp_ctl; A.hist = ctx->hist;
-        A.hello_ticks = 200000;        // 2 ms
+        A.hello_ticks = ctx->opt_lp_hello;   // 2 ms (test hook 97: negative = workgroup 0 withholds its record for that long)
         A.spin_ticks = 100000000;      // 1 s
         A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
         void *args[] = {&A};
@@ -4000,6 +4001,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_broken = false; break; // undocumented: rendezvous limit of k_lds2opt (tests)
     case 98: // undocumented: per-workgroup phase stamps of the pipelined sweep (single tour)
         ctx->opt_stamps = value ? 1 : 0; drop_graphs(ctx);
         if (value && !ctx->d_stamps) HIP_TRY(hipMalloc(&ctx->d_stamps, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
