@@ -773,10 +773,11 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     auto key_w = [&](K k) __attribute__((always_inline)) { return (unsigned)(k >> WSH); };
     auto key_id = [&](K k) __attribute__((always_inline)) { return (int)(KEY32 ? (unsigned)k & 0x1ffffu : (unsigned)k); };
 
-    // a single wave: LDS operations of one wave complete in order, so lane 0's update of the visited bits needs no
-    // workgroup barrier before the next step reads them -- only the compiler must not move LDS accesses across it
-    // (__syncthreads() would also wait for the global store of ord[step], a full memory round trip per step)
-#define NN_WAVE_SYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+    // a single wave: LDS operations of one wave complete in order, so lane 0's update of the visited bits (a ds_or
+    // without return: no read trip) needs neither a barrier nor a wait before the next step reads them -- only the
+    // compiler must not move LDS accesses across it (__syncthreads() would also wait for the global store of
+    // ord[step], a full memory round trip per step; an s_waitcnt lgkmcnt(0) for the LDS write: 0.05 us per step)
+#define NN_WAVE_SYNC() asm volatile("" ::: "memory")
     const unsigned wlb2 = (unsigned)edge_w<KIND>(0.0, 0.0, fmax(0.0, 2.0 * A.cell - A.eps), 0.0);   // weight bound of the first square
     const int jl5 = lane / 12, k5 = lane - jl5 * 12;          // first square: 5 grid rows x 12 lanes
 
@@ -857,7 +858,7 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
             P.x = lane_f64(Q.x, src); P.y = lane_f64(Q.y, src); ccell = __builtin_amdgcn_readlane(qc, src);
         }
         total += (double)key_w(win);
-        if (lane == 0) { ord[step] = key_id(win); vis[cur >> 5] |= 1u << (cur & 31); }
+        if (lane == 0) { ord[step] = key_id(win); __hip_atomic_fetch_or(&vis[cur >> 5], 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
         NN_WAVE_SYNC();
     }
 #undef NN_WAVE_SYNC
