@@ -3588,7 +3588,14 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
             while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
             HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         }
-        HIP_TRY(hipLaunchKernel(fn, dim3(W), dim3(LP_BT), args, lds, ctx->stream));
+        {
+            const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(LP_BT), args, lds, ctx->stream);
+            if (le != hipSuccess) {                    // (e.g. a device that does not grant 160 KiB of LDS to one workgroup)
+                (void)hipGetLastError();
+                if (first) { ctx->lp_broken = true; return E_OK; }
+                return fail(ctx, E_INTERNAL, "LDS-resident descent: launch failed: %s", hipGetErrorString(le));
+            }
+        }
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
         HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
