@@ -1147,3 +1147,54 @@ def test_lds_resident_rendezvous_failure_falls_back(T, O, instances, golden):
         assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("edges", [0, 6])
+@pytest.mark.parametrize("name,k", [("kroA100", 400), ("n200_s3", 400), ("pr1002", 200), ("n1000_s123", 200), ("n1024_s1", 150)])
+def test_lds_resident_tabu_walk(eng, T, O, instances, name, k, edges, persist):
+    """mh_TabuSearch's k iterations in ONE launch (k_lds2opt<., true>: matrix, labels and the nodes' ages in LDS, cells
+    of tour neighbours poisoned and patched per move, linear tenure policy in the kernel): from the 2-opt local optimum
+    of NN(0) -- where every admissible move goes uphill -- the cost after EVERY iteration, the final tour, the best
+    tour and its cost equal the oracle's; packed 16-bit form (costs <= 8190: kroA100, n200) and the 32-bit form"""
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST_EDGES, edges)
+    seed, cost = O.nn_tour(c, 0)
+    _, cost = O.two_opt(c, seed)
+    cost = O.tour_cost(c, seed)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, k, want_trace=True)
+    assert eng.info()["persist"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed)
+    assert best_cost == obc and np.array_equal(best, obest)
+    assert O.valid_tour(best) and O.tour_cost(c, best) == best_cost
+
+
+def test_lds_resident_tabu_from_nn_and_ties(eng, T, O, instances, persist):
+    """the tabu walk from a raw NN tour (improving moves first, then uphill) and on a caller matrix full of ties"""
+    xy, c = setup(eng, T, O, instances, "n200_s3", 3, 0)
+    seed, cost = O.nn_tour(c, 5)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 500, want_trace=True)
+    assert eng.info()["persist"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, 500)
+    assert np.array_equal(trace, otrace) and final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)
+    r = np.random.RandomState(12)
+    n = 160
+    m = r.randint(1, 12, size=(n, n)).astype(np.float64)
+    m = np.triu(m, 1); m = m + m.T
+    np.fill_diagonal(m, -1.0)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_costs(m)
+    perm = r.permutation(n).astype(np.int32)
+    seed = np.empty(n, dtype=np.int32); seed[perm] = np.roll(perm, -1)
+    cost = O.tour_cost(m, seed)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 300, want_trace=True)
+    assert eng.info()["persist"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(m, oseed, cost, 300)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)

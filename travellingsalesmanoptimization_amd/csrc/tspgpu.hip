@@ -338,6 +338,7 @@ __global__ void __launch_bounds__(256) k_inspect(const double *__restrict__ m, i
     if (j > i && m[(size_t)j * ld + i] != x) flags[1] = 1;
     if (i == j ? x != -1.0 : !(r == x && x >= 0.0 && x <= 65534.0)) flags[2] = 1;
     if (i != j && !(x <= 16383.0)) flags[3] = 1;
+    if (i != j && !(x <= 8190.0)) flags[4] = 1;
 }
 
 template <typename TD>
@@ -2811,10 +2812,12 @@ struct tspgpu_ctx {
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
+    int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk: the best tour by array cell [ld], its direction and flag [2]
     bool lp_broken = false;    // the grid did not come up co-resident once: keep to the one-launch-per-sweep path
     bool lp_used = false;      // the last descent ran in k_lds2opt
-    bool lp_attr[2] = {false, false};
+    bool lp_attr[4] = {false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
+    bool max8k = false;        // ... <= 8190 (the tabu form of the packed loop: a poisoned pair must exceed every valid delta)
 
     Fused F{};                 // fused path state (allocated on first use, capacity fcap)
     int fcap = 0;
@@ -3527,7 +3530,7 @@ static int run_fused(tspgpu_ctx *ctx, int slot0, int ntours, double time_left_s,
 }
 
 // The LDS-resident descent (k_lds2opt) where it applies: uint16 cells, one tour, a whole chip whose LDS holds the matrix.
-static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds)
+static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, bool tabu = false)
 {
     const int n = ctx->n;
     if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 64 || n > 4096) return false;
@@ -3535,7 +3538,7 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds)
     if (ctx->opt_persist_edges > e) e = ctx->opt_persist_edges;
     if (e > LP_EMAX || e > n / 4) return false;
     const size_t nl = (size_t)((n + 7) & ~7);
-    lds = (size_t)(e + 1) * nl * 2 + nl * 4 + std::max<size_t>(nl * 2, 256);
+    lds = (size_t)(e + 1) * nl * 2 + nl * 4 + std::max<size_t>(nl * 2, 256) + (tabu ? nl * 2 : 0);   // (+ the nodes' ages)
     if (lds > ctx->lds_max) return false;
     E = e; W = (n + e - 1) / e;
     return W <= ctx->cus && W <= LP_BT;
@@ -3544,21 +3547,30 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds)
 // *ran = false: nothing was touched (does not apply, or the grid did not come up co-resident): the caller takes the
 // one-launch-per-sweep path.  Deadline: launches with a sweep budget of a third of the time left, measured per sweep;
 // every launch leaves a consistent tour (the sweep that ran is applied, refinment.c:17-26).
-static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *deadline_hit, bool *ran)
+struct PersistTabu { int k, tenure, t_min, t_max, up; double best; };
+
+static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *deadline_hit, bool *ran, const PersistTabu *tabu = nullptr)
 {
     *ran = false;
     int E = 0, W = 0;
     size_t lds = 0;
-    if (ctx->lp_broken || !persist_fits(ctx, E, W, lds)) return E_OK;
+    if (ctx->lp_broken || !persist_fits(ctx, E, W, lds, tabu != nullptr)) return E_OK;
     if (!ctx->d_lp_slots) {
         HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));      // exchange slots, then the control words
         HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
     }
-    const int pk = ctx->max16k ? 1 : 0;
-    const void *fn = pk ? (const void *)k_lds2opt<true> : (const void *)k_lds2opt<false>;
-    if (!ctx->lp_attr[pk]) {
+    if (tabu && ctx->lp_best_n < ctx->ld) {
+        if (ctx->d_lp_best) hipFree(ctx->d_lp_best);
+        ctx->d_lp_best = nullptr; ctx->lp_best_n = 0;
+        HIP_TRY(hipMalloc(&ctx->d_lp_best, ((size_t)ctx->ld + 16) * 4));
+        ctx->lp_best_n = ctx->ld;
+    }
+    const int pk = (tabu ? ctx->max8k : ctx->max16k) ? 1 : 0;
+    const void *fn = tabu ? (pk ? (const void *)k_lds2opt<true, true> : (const void *)k_lds2opt<false, true>)
+                          : (pk ? (const void *)k_lds2opt<true, false> : (const void *)k_lds2opt<false, false>);
+    if (!ctx->lp_attr[pk + (tabu ? 2 : 0)]) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
-        ctx->lp_attr[pk] = true;
+        ctx->lp_attr[pk + (tabu ? 2 : 0)] = true;
     }
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
     if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; *ran = true; ctx->lp_used = true; return E_OK; }
@@ -3574,6 +3586,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         }
         int *d_ctl = reinterpret_cast<int *>(ctx->d_lp_slots + (size_t)2 * W * 8);   // (one memset for both)
         HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64 + 64, ctx->stream));
+        if (tabu) HIP_TRY(hipMemsetAsync(ctx->d_lp_best + ctx->ld, 0, 8, ctx->stream));
         PersistArgs A;
         memset(&A, 0, sizeof A);
         A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
@@ -3582,6 +3595,12 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         A.hello_ticks = ctx->opt_lp_hello;   // 2 ms (test hook 97: negative = workgroup 0 withholds its record for that long)
         A.spin_ticks = 100000000;      // 1 s
         A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
+        if (tabu) {
+            A.budget = -1;
+            A.tabu_k = tabu->k; A.tenure0 = tabu->tenure; A.t_min = tabu->t_min; A.t_max = tabu->t_max; A.up0 = tabu->up;
+            A.best0 = tabu->best; A.best_ord = ctx->d_lp_best; A.best_dir = ctx->d_lp_best + ctx->ld; A.trace = ctx->d_trace;
+            A.best_out = &ctx->d_tabu->best_cost;
+        }
         void *args[] = {&A};
         const double t0 = now_s();
         if (ctx->opt_timing) {
@@ -3597,6 +3616,11 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
             }
         }
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        if (tabu) {
+            hipLaunchKernelGGL(k_lds_best_succ, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lp_best, ctx->d_lp_best + ctx->ld,
+                               ctx->d_best_succ, ctx->n);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 16, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
@@ -3983,6 +4007,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_flags) hipFree(ctx->d_flags);
     if (ctx->d_lp_slots) hipFree(ctx->d_lp_slots);
     if (ctx->h_ord) hipHostFree(ctx->h_ord);
+    if (ctx->d_lp_best) hipFree(ctx->d_lp_best);
     if (ctx->ev_ord) hipEventDestroy(ctx->ev_ord);
     if (ctx->h_lp) hipHostFree(ctx->h_lp);
     if (ctx->d_trace) hipFree(ctx->d_trace);
@@ -4150,6 +4175,7 @@ int tspgpu_build_costs(tspgpu_ctx *ctx, double *host_out)
     if (rc) return rc;
     ctx->symmetric = true; // Euclidean
     ctx->max16k = ctx->cost_bound <= 16383.0;
+    ctx->max8k = ctx->cost_bound <= 8190.0;
     ctx->have_costs = true;
     ctx->built = true;
     ctx->plan_kernel = 0;
@@ -4176,14 +4202,15 @@ int tspgpu_set_costs(tspgpu_ctx *ctx, const double *host_costs, int n)
     HIP_TRY(hipMalloc(&stage, cells * 8));
     HIP_TRY(hipMemsetAsync(stage, 0, cells * 8, ctx->stream));
     HIP_TRY(hipMemcpy2DAsync(stage, (size_t)ld * 8, host_costs, (size_t)n * 8, (size_t)n * 8, n, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 16, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_flags, 0, 32, ctx->stream));
     hipLaunchKernelGGL(k_inspect, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, stage, n, ld, ctx->d_flags);
     HIP_TRY(hipGetLastError());
-    int flags[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 16, hipMemcpyDeviceToHost, ctx->stream));
+    int flags[5] = {0, 0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(flags, ctx->d_flags, 20, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     const bool integral = flags[0] == 0, fits16 = flags[2] == 0;
     ctx->max16k = fits16 && flags[3] == 0;
+    ctx->max8k = fits16 && flags[4] == 0;
     ctx->symmetric = flags[1] == 0;
     if ((ctx->opt_elem == TSPGPU_ELEM_I32 && !integral) || (ctx->opt_elem == TSPGPU_ELEM_U16 && !fits16)) {
         hipFree(stage);
@@ -4404,7 +4431,15 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
     if (tenure == t_max || tenure == t_min) up = !up;
     tenure += up ? 1 : -1;
     if ((rc = tabu_prepare(ctx, nullptr, tenure, 0, t_min, t_max, up, 1, *cost))) return rc;
-    if (k > 0 && (rc = run_sweeps(ctx, 0, 1, true, k, -1, nullptr))) return rc;
+    bool ran = false;
+    ctx->lp_used = false;
+    if (k > 0 && ctx->symmetric && (ctx->opt_persist == 2 || (ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1))) {
+        // the whole walk in one launch, matrix and ages in LDS (k_lds2opt<., true>) where it applies
+        const PersistTabu pt = {k, tenure, t_min, t_max, up, *cost};
+        if ((rc = run_persist(ctx, 0, -1, nullptr, &ran, &pt))) return rc;
+        if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident tabu walk does not apply (uint16 cells, n in [64, ~3800], one idle chip)");
+    }
+    if (k > 0 && !ran && (rc = run_sweeps(ctx, 0, 1, true, k, -1, nullptr))) return rc;
     if (trace && k > 0) HIP_TRY(hipMemcpyAsync(trace, ctx->d_trace, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
     TabuState ts;
     HIP_TRY(hipMemcpyAsync(&ts, ctx->d_tabu, sizeof ts, hipMemcpyDeviceToHost, ctx->stream));
