@@ -66,8 +66,9 @@ enum {
     TSPGPU_OPT_SWEEP_CAP = 13,  /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
                                    reference's behaviour; >= 0 caps every local search: tests and bounded runs) */
     TSPGPU_OPT_PERSIST = 16,    /* single-tour descent with the whole uint16 matrix resident in LDS, one launch per descent
-                                   (n <= 4096, one workgroup per CU): 0 never, 1 (default) where it applies -- falls back to
-                                   one launch per sweep when the grid cannot be co-resident --, 2 or fail with code 8 */
+                                   (n <= 4096, one workgroup per CU), and tspgpu_tabu_search's walk the same way (n up to
+                                   about 3800): 0 never, 1 (default) where it applies -- falls back to one launch per sweep
+                                   when the grid cannot be co-resident --, 2 or fail with code 8 */
     TSPGPU_OPT_PERSIST_EDGES = 17 /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16) */
 };
 
