@@ -543,6 +543,36 @@ def main():
     if rank != 0:
         return
 
+    # ---- mh_TabuSearch's walk (metaheuristic.c:86-245): k iterations from the 2-opt local optimum, LDS-resident and not
+    tabu = None
+    if aux and not args.no_sizes:
+        def tabu_leg():
+            k, out = 2000, {}
+            for tn in (1024, 3584):
+                e4 = T.Engine(local)
+                try:
+                    e4.set_option(T.OPT_ELEM, T.ELEM_U16)
+                    e4.set_points(reference_points(tn, 123)); e4.build_costs()
+                    seed0, c0 = e4.nn_tour(0)
+                    c0, _, _ = e4.two_opt(seed0)
+                    row = {"iterations": k, "from": "2-opt local optimum of NN(0), uniform-random seed 123"}
+                    for mode, name in ((1, "lds_resident"), (0, "sweep_apply_kernels")):
+                        e4.set_option(T.OPT_PERSIST, mode)
+                        ts = []
+                        for _ in range(2):
+                            s0 = seed0.copy()
+                            t1 = time.perf_counter()
+                            _, bc, fc, _ = e4.tabu_search(s0, c0, k)
+                            ts.append(time.perf_counter() - t1)
+                        row[name] = {"us_per_iteration": 1e6 * min(ts) / k, "kernel": "k_lds2opt<.,true>" if e4.info()["persist"] else "k_sweep_*<TABU> + k_apply",
+                                     "best_cost": bc, "final_cost": fc}
+                    row["same_walk"] = row["lds_resident"]["final_cost"] == row["sweep_apply_kernels"]["final_cost"]
+                    out[str(tn)] = row
+                finally:
+                    e4.close()
+            return out
+        tabu = guarded(tabu_leg)
+
     # ---- the drop-in binary: C host layer, multi-start sharded in C over the N devices of this run, RCCL exchange.
     # A child process (its own HIP context); at N > 1 the other ranks have left and released their devices.
     host_c = None
@@ -596,6 +626,7 @@ def main():
         "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
         "roofline": roof, "roofline_one_launch_per_sweep": roof_fused, "roofline_build": broof, "cpu_baseline": base,
         "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
+        "tabu_walk": tabu,
     }
     if base and "value" in base:
         out["gpu_over_cpu"] = out["value"] / base["value"]
