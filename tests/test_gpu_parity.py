@@ -1198,3 +1198,32 @@ def test_lds_resident_tabu_from_nn_and_ties(eng, T, O, instances, persist):
     bad = np.nonzero(trace != otrace)[0]
     assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
     assert final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)
+
+
+@pytest.mark.parametrize("n", [64, 65, 71, 72, 88, 127, 129, 255, 256, 257, 264, 513, 1000, 1016, 2047, 2056, 3000, 3833, 3840, 4088, 4095, 4096])
+def test_lds_resident_size_sweep(eng, T, O, n, persist):
+    """sizes around every boundary of k_lds2opt's geometry -- n % 8 != 0 (padded rows, the copy of cell 0), n % 16 == 8
+    (every pair by both owners), n % 16 == 0 (by one), one edge per workgroup, the last workgroup overlapping its
+    neighbour, LDS full (4096) -- : 2-opt descent steps and a tabu walk against the oracle, move by move"""
+    xy = O.random_points(n, 1000 + n)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, n // 3)
+    g = succ.copy(); gcost = cost
+    for _ in range(12):
+        d, cost, mv = O.two_opt_once(c, succ, cost)
+        gd, gcost = eng.two_opt_once(g, gcost)
+        assert eng.info()["persist"] == 1
+        assert gd == d and gcost == cost and np.array_equal(g, succ), (n, mv, d, gd)
+        if d >= -1e-7:
+            break
+    fits_tabu = eng.info()["persist_lds"] + 2 * ((n + 7) & ~7) <= 160 * 1024
+    k = 25
+    oseed = g.copy()
+    if not fits_tabu:
+        eng.set_option(T.OPT_PERSIST, 1)             # (the ages do not fit: asked for, not insisted on)
+    best, best_cost, final, trace = eng.tabu_search(g, gcost, k, want_trace=True)
+    assert eng.info()["persist"] == (1 if fits_tabu else 0)
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
+    assert np.array_equal(trace, otrace) and final == ofinal and np.array_equal(g, oseed) and np.array_equal(best, obest), n
