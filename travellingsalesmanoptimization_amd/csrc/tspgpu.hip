@@ -33,6 +33,7 @@
 // There is no CPU fallback anywhere in this file.
 
 #include <hip/hip_runtime.h>
+#include <cstddef>
 
 #include <algorithm>
 #include <chrono>
@@ -3599,7 +3600,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
             A.budget = -1;
             A.tabu_k = tabu->k; A.tenure0 = tabu->tenure; A.t_min = tabu->t_min; A.t_max = tabu->t_max; A.up0 = tabu->up;
             A.best0 = tabu->best; A.best_ord = ctx->d_lp_best; A.best_dir = ctx->d_lp_best + ctx->ld; A.trace = ctx->d_trace;
-            A.best_out = &ctx->d_tabu->best_cost;
+            A.best_out = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost));
         }
         void *args[] = {&A};
         const double t0 = now_s();
