@@ -62,7 +62,9 @@ enum {
     TSPGPU_OPT_PIPE2 = 15,      /* one-launch-per-sweep kernel over streamed rows: 1 (default) two tour edges per barrier
                                    interval where four rows fit LDS, 0 one edge per barrier over three row buffers */
     TSPGPU_OPT_NN_KERNEL = 14,  /* nearest-neighbour construction: 0 auto (the grid kernel whenever the weights come from
-                                   the uploaded points, else the matrix kernel), 1 matrix / strided kernels always */
+                                   the uploaded points -- with every point's 3 nearest neighbours in LDS where they fit --,
+                                   else the matrix kernel), 1 matrix / strided kernels always, 3 the grid kernel without
+                                   the neighbour lists */
     TSPGPU_OPT_SWEEP_CAP = 13,  /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
                                    reference's behaviour; >= 0 caps every local search: tests and bounded runs) */
     TSPGPU_OPT_PERSIST = 16,    /* single-tour descent with the whole uint16 matrix resident in LDS, one launch per descent

@@ -688,16 +688,23 @@ struct GridArgs {
     const int *cstart;       // [G*G + 1] first sorted position of every cell
     int G;
     double cell, eps;
+    const unsigned *knn;     // [n][NN_K] nearest neighbours of every point (k_knn_build), nullptr: none
 };
+
+constexpr int NN_K = 3;      // list length: the next node of an NN walk is among the 3 nearest in 83 % of the steps (n = 4096)
 
 constexpr int NN_TAIL = 256;
 
 // LDS_PTS / LDS_CS: points + node ids + cells / cell starts staged in LDS -- compile-time, so that every access is a
 // ds_read with a 32-bit address (a run-time choice of pointer turns them all into flat loads).  KEY32: weights below
 // 2^15 and n <= 2^17, the candidate key (weight, node) is ONE 32-bit word and a reduction step one v_min_u32.
-template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32>
+// KNN: the NN_K nearest neighbours of every point by (weight, node), certified complete (weight below the bound of the
+// first square; k_knn_build), sit in LDS: the first unvisited one IS the nearest unvisited node -- two LDS trips and a
+// ballot instead of the candidate scan; the scan runs only when all of them are visited (17 % of the steps at n = 4096).
+template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32, bool KNN = false>
 __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
 {
+    static_assert(!KNN || (LDS_PTS && KEY32), "the neighbour lists ride on the LDS-resident 32-bit-key form");
     typedef typename std::conditional<KEY32, unsigned, u64>::type K;
     constexpr K NONE = (K)~(K)0;
     constexpr int WSH = KEY32 ? 17 : 32;
@@ -715,6 +722,8 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     double2 *pts_l = reinterpret_cast<double2 *>(cs_l + (LDS_CS ? ((ncs + 3) & ~3) : 0));
     int *idx_l = reinterpret_cast<int *>(pts_l + (LDS_PTS ? n : 0));
     int *cell_l = idx_l + (LDS_PTS ? n : 0);
+    unsigned *knn_l = reinterpret_cast<unsigned *>(cell_l + (LDS_PTS ? n : 0));
+    if constexpr (KNN) for (int i = lane; i < n * NN_K; i += 64) knn_l[i] = A.knn[i];
     for (int w = lane; w < nwords; w += 64) vis[w] = 0;
     if constexpr (LDS_CS) for (int i = lane; i < ncs; i += 64) cs_l[i] = A.cstart[i];
     if constexpr (LDS_PTS) for (int i = lane; i < n; i += 64) { pts_l[i] = A.gxy[i]; idx_l[i] = A.gidx[i]; cell_l[i] = A.gcell[i]; }
@@ -783,7 +792,25 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     const unsigned wlb2 = (unsigned)edge_w<KIND>(0.0, 0.0, fmax(0.0, 2.0 * A.cell - A.eps), 0.0);   // weight bound of the first square
     const int jl5 = lane / 12, k5 = lane - jl5 * 12;          // first square: 5 grid rows x 12 lanes
 
+    bool pvalid = true;                             // P / ccell are those of `cur` (a list hit moves on without them)
     for (; step <= grid_steps; step++) {
+        if constexpr (KNN) {
+            const unsigned e = lane < NN_K ? knn_l[cur * NN_K + lane] : ~0u;     // (weight << 17 | sorted position), ascending by (weight, node)
+            const unsigned q = e & 0x1ffffu;
+            const bool unv = e != ~0u && !((vis[min(q, (unsigned)n - 1) >> 5] >> (q & 31)) & 1u);
+            const unsigned long long bal = __ballot(unv);
+            if (bal) {
+                const int src = __ffsll(bal) - 1;
+                const unsigned we = (unsigned)__builtin_amdgcn_readlane((int)e, src);
+                cur = (int)(we & 0x1ffffu);
+                total += (double)(we >> 17);
+                pvalid = false;
+                if (lane == 0) { ord[step] = gidx(cur); __hip_atomic_fetch_or(&vis[cur >> 5], 1u << (cur & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT); }
+                NN_WAVE_SYNC();
+                continue;
+            }
+            if (!pvalid) { P = pts(cur); ccell = __builtin_amdgcn_readfirstlane(gcell(cur)); pvalid = true; }
+        }
         const int cx = ccell & 0xffff, cy = ccell >> 16;
         K best = NONE;                              // lane's best candidate: (weight, node) ...
         int bestp = 0;                              // ... and its sorted position
@@ -865,6 +892,7 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     }
 #undef NN_WAVE_SYNC
 
+    if constexpr (KNN) { if (!pvalid) P = pts(cur); }
     // ---- the last <= NN_TAIL unvisited nodes: in registers, four per lane
     {
         const int remaining = n - step;
@@ -919,6 +947,42 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
             A.S.cost[t] = total;
             A.S.status[t] = 0;
         }
+    }
+}
+
+// The NN_K nearest neighbours of every point, by (weight, node) as heuristics.c:253-263 orders them, from the first square
+// of the grid (cells within 2 of the point's): entry j = (weight << 17 | sorted position), ~0 where the list cannot be
+// certified -- a weight not below the bound of everything outside the square (the bound k_nn_grid expands on).  Every
+// point that is not in the list has a larger (weight, node) than every certified entry, so the first unvisited certified
+// entry of the current node is the nearest unvisited node.  One thread per point; built once per instance.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_knn_build(GridArgs A, unsigned *__restrict__ out)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int n = A.n, G = A.G;
+    if (p >= n) return;
+    const double2 P = A.gxy[p];
+    const int cc = A.gcell[p], cx = cc & 0xffff, cy = cc >> 16;
+    u64 best[NN_K];                                 // (weight << 34 | node << 17 | sorted position), ascending
+#pragma unroll
+    for (int j = 0; j < NN_K; j++) best[j] = ~0ull;
+    for (int y = max(0, cy - 2); y <= min(G - 1, cy + 2); y++) {
+        const int s1 = A.cstart[y * G + max(0, cx - 2)], e1 = A.cstart[y * G + min(G - 1, cx + 2) + 1];
+        for (int q = s1; q < e1; q++) {
+            if (q == p) continue;
+            const double2 Q = A.gxy[q];
+            u64 key = ((u64)(unsigned)edge_w<KIND>(P.x, P.y, Q.x, Q.y) << 34) | ((u64)(unsigned)A.gidx[q] << 17) | (unsigned)q;
+#pragma unroll
+            for (int j = 0; j < NN_K; j++) { if (key < best[j]) { const u64 t = best[j]; best[j] = key; key = t; } }
+        }
+    }
+    const bool whole2 = cx - 2 <= 0 && cy - 2 <= 0 && cx + 2 >= G - 1 && cy + 2 >= G - 1;
+    const unsigned wlb2 = (unsigned)edge_w<KIND>(0.0, 0.0, fmax(0.0, 2.0 * A.cell - A.eps), 0.0);
+#pragma unroll
+    for (int j = 0; j < NN_K; j++) {
+        const unsigned w = (unsigned)(best[j] >> 34);
+        const bool ok = best[j] != ~0ull && (whole2 || w < wlb2) && w < 32767u;
+        out[(size_t)p * NN_K + j] = ok ? (w << 17) | (unsigned)(best[j] & 0x1ffffu) : ~0u;
     }
 }
 
@@ -2773,6 +2837,7 @@ struct tspgpu_ctx {
     double2 *d_spts = nullptr; size_t spts_cap = 0;
     // uniform grid over the points for the grid NN (k_nn_grid): built on the host in tspgpu_set_points
     double2 *d_gxy = nullptr; int *d_gidx = nullptr, *d_gpos = nullptr, *d_cstart = nullptr, *d_gcell = nullptr;
+    unsigned *d_knn = nullptr;   // [n][NN_K] neighbour lists of k_nn_grid's KNN form (built at the first single-tour NN)
     int grid_G = 0, grid_max_occ = 0; bool grid_ok = false;
     double grid_x0 = 0, grid_y0 = 0, grid_cell = 1, grid_inv = 0, grid_eps = 0;
     int opt_nn = 0;          // 0 auto, 1 matrix / strided kernels, 2 grid kernel
@@ -2893,9 +2958,9 @@ static void free_tour_scratch(tspgpu_ctx *ctx)
 
 static void free_grid(tspgpu_ctx *ctx)
 {
-    void *ptrs[] = {ctx->d_gxy, ctx->d_gidx, ctx->d_gpos, ctx->d_cstart, ctx->d_gcell};
+    void *ptrs[] = {ctx->d_gxy, ctx->d_gidx, ctx->d_gpos, ctx->d_cstart, ctx->d_gcell, ctx->d_knn};
     for (void *p : ptrs) if (p) hipFree(p);
-    ctx->d_gxy = nullptr; ctx->d_gidx = ctx->d_gpos = ctx->d_cstart = ctx->d_gcell = nullptr;
+    ctx->d_gxy = nullptr; ctx->d_gidx = ctx->d_gpos = ctx->d_cstart = ctx->d_gcell = nullptr; ctx->d_knn = nullptr;
     ctx->grid_G = 0; ctx->grid_ok = false;
 }
 
@@ -3886,8 +3951,9 @@ static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, doubl
     return E_OK;
 }
 
-template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32)
+template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32, bool knn = false)
 {
+    if (knn) return (const void *)k_nn_grid<KIND, true, true, true, true>;
     if (lds_pts && lds_cs) return key32 ? (const void *)k_nn_grid<KIND, true, true, true> : (const void *)k_nn_grid<KIND, true, true, false>;
     if (lds_pts) return (const void *)k_nn_grid<KIND, true, false, false>;
     return lds_cs ? (const void *)k_nn_grid<KIND, false, true, false> : (const void *)k_nn_grid<KIND, false, false, false>;
@@ -3921,8 +3987,24 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
         if (lp) lds += (size_t)n * 24;
         const bool key32 = ctx->cost_bound < 32767.0 && n <= 131072;      // (weight << 17 | node) in one 32-bit word, below the "none" key
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
-        const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>(lp, lc, key32) : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>(lp, lc, key32)
-                       : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>(lp, lc, key32) : nn_grid_fn<TSPGPU_CEIL_2D>(lp, lc, key32);
+        // ... and, where they fit beside them, the 3 nearest neighbours of every point (built once per instance)
+        const bool knn = lp && lc && key32 && ctx->opt_nn != 3 && lds + (size_t)n * NN_K * 4 <= ctx->lds_max;
+        A.knn = nullptr;
+        if (knn) {
+            if (!ctx->d_knn) {
+                HIP_TRY(hipMalloc(&ctx->d_knn, (size_t)n * NN_K * 4));
+                const dim3 g((n + 255) / 256), b(256);
+                if (kind == TSPGPU_EUC_2D) hipLaunchKernelGGL((k_knn_build<TSPGPU_EUC_2D>), g, b, 0, ctx->stream, A, ctx->d_knn);
+                else if (kind == TSPGPU_ATT) hipLaunchKernelGGL((k_knn_build<TSPGPU_ATT>), g, b, 0, ctx->stream, A, ctx->d_knn);
+                else if (kind == KIND_CEIL_INT) hipLaunchKernelGGL((k_knn_build<KIND_CEIL_INT>), g, b, 0, ctx->stream, A, ctx->d_knn);
+                else hipLaunchKernelGGL((k_knn_build<TSPGPU_CEIL_2D>), g, b, 0, ctx->stream, A, ctx->d_knn);
+                HIP_TRY(hipGetLastError());
+            }
+            A.knn = ctx->d_knn;
+            lds += (size_t)n * NN_K * 4;
+        }
+        const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>(lp, lc, key32, knn) : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>(lp, lc, key32, knn)
+                       : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>(lp, lc, key32, knn) : nn_grid_fn<TSPGPU_CEIL_2D>(lp, lc, key32, knn);
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         void *args[] = {&A};
         HIP_TRY(hipLaunchKernel(fn, dim3(count), dim3(64), args, lds, ctx->stream));
@@ -4061,7 +4143,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_broken = false; break;
     case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LP_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LP_EMAX); ctx->opt_persist_edges = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
-    case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
+    case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
     case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
     default: return fail(ctx, E_INVALID, "unknown option %d", option);
     }
