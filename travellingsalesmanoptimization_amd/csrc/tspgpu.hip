@@ -701,10 +701,12 @@ constexpr int NN_TAIL = 256;
 // KNN: the NN_K nearest neighbours of every point by (weight, node), certified complete (weight below the bound of the
 // first square; k_knn_build), sit in LDS: the first unvisited one IS the nearest unvisited node -- two LDS trips and a
 // ballot instead of the candidate scan; the scan runs only when all of them are visited (17 % of the steps at n = 4096).
-template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32, bool KNN = false>
+// KNN = 1: lists in LDS (single tours), 2: read from global memory (batches: one wave per start, the 12 n bytes stay in L1 / L2).
+template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32, int KNN = 0>
 __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
 {
-    static_assert(!KNN || (LDS_PTS && KEY32), "the neighbour lists ride on the LDS-resident 32-bit-key form");
+    static_assert(KNN == 0 || KEY32, "the neighbour lists hold 32-bit keys");
+    static_assert(KNN != 1 || LDS_PTS, "lists in LDS ride on the LDS-resident form");
     typedef typename std::conditional<KEY32, unsigned, u64>::type K;
     constexpr K NONE = (K)~(K)0;
     constexpr int WSH = KEY32 ? 17 : 32;
@@ -723,7 +725,7 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     int *idx_l = reinterpret_cast<int *>(pts_l + (LDS_PTS ? n : 0));
     int *cell_l = idx_l + (LDS_PTS ? n : 0);
     unsigned *knn_l = reinterpret_cast<unsigned *>(cell_l + (LDS_PTS ? n : 0));
-    if constexpr (KNN) for (int i = lane; i < n * NN_K; i += 64) knn_l[i] = A.knn[i];
+    if constexpr (KNN == 1) for (int i = lane; i < n * NN_K; i += 64) knn_l[i] = A.knn[i];
     for (int w = lane; w < nwords; w += 64) vis[w] = 0;
     if constexpr (LDS_CS) for (int i = lane; i < ncs; i += 64) cs_l[i] = A.cstart[i];
     if constexpr (LDS_PTS) for (int i = lane; i < n; i += 64) { pts_l[i] = A.gxy[i]; idx_l[i] = A.gidx[i]; cell_l[i] = A.gcell[i]; }
@@ -795,7 +797,7 @@ __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
     bool pvalid = true;                             // P / ccell are those of `cur` (a list hit moves on without them)
     for (; step <= grid_steps; step++) {
         if constexpr (KNN) {
-            const unsigned e = lane < NN_K ? knn_l[cur * NN_K + lane] : ~0u;     // (weight << 17 | sorted position), ascending by (weight, node)
+            const unsigned e = lane < NN_K ? (KNN == 1 ? knn_l[cur * NN_K + lane] : A.knn[(size_t)cur * NN_K + lane]) : ~0u;   // (weight << 17 | sorted position), ascending by (weight, node)
             const unsigned q = e & 0x1ffffu;
             const bool unv = e != ~0u && !((vis[min(q, (unsigned)n - 1) >> 5] >> (q & 31)) & 1u);
             const unsigned long long bal = __ballot(unv);
@@ -3951,9 +3953,10 @@ static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, doubl
     return E_OK;
 }
 
-template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32, bool knn = false)
+template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32, int knn = 0)
 {
-    if (knn) return (const void *)k_nn_grid<KIND, true, true, true, true>;
+    if (knn == 1) return (const void *)k_nn_grid<KIND, true, true, true, 1>;
+    if (knn == 2) return lds_cs ? (const void *)k_nn_grid<KIND, false, true, true, 2> : (const void *)k_nn_grid<KIND, false, false, true, 2>;
     if (lds_pts && lds_cs) return key32 ? (const void *)k_nn_grid<KIND, true, true, true> : (const void *)k_nn_grid<KIND, true, true, false>;
     if (lds_pts) return (const void *)k_nn_grid<KIND, true, false, false>;
     return lds_cs ? (const void *)k_nn_grid<KIND, false, true, false> : (const void *)k_nn_grid<KIND, false, false, false>;
@@ -3988,7 +3991,8 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
         const bool key32 = ctx->cost_bound < 32767.0 && n <= 131072;      // (weight << 17 | node) in one 32-bit word, below the "none" key
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
         // ... and, where they fit beside them, the 3 nearest neighbours of every point (built once per instance)
-        const bool knn = lp && lc && key32 && ctx->opt_nn != 3 && lds + (size_t)n * NN_K * 4 <= ctx->lds_max;
+        // (in LDS for a single tour; batches and tours whose points do not fit LDS read them from global memory)
+        const int knn = !key32 || ctx->opt_nn == 3 ? 0 : (lp && lc && lds + (size_t)n * NN_K * 4 <= ctx->lds_max) ? 1 : !lp ? 2 : 0;
         A.knn = nullptr;
         if (knn) {
             if (!ctx->d_knn) {
@@ -4001,7 +4005,7 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
                 HIP_TRY(hipGetLastError());
             }
             A.knn = ctx->d_knn;
-            lds += (size_t)n * NN_K * 4;
+            if (knn == 1) lds += (size_t)n * NN_K * 4;
         }
         const void *fn = kind == TSPGPU_EUC_2D ? nn_grid_fn<TSPGPU_EUC_2D>(lp, lc, key32, knn) : kind == TSPGPU_ATT ? nn_grid_fn<TSPGPU_ATT>(lp, lc, key32, knn)
                        : kind == KIND_CEIL_INT ? nn_grid_fn<KIND_CEIL_INT>(lp, lc, key32, knn) : nn_grid_fn<TSPGPU_CEIL_2D>(lp, lc, key32, knn);
