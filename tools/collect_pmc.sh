@@ -9,7 +9,7 @@
 out=gpurun_out/${1:-pmc}
 rm -rf "$out"; mkdir -p "$out"
 export TMPDIR=/tmp
-B="--warmup 0 --lean"
+B="--warmup 0 --lean --persist 0"     # the one-launch-per-sweep kernels (the LDS-resident descent: tools/collect_lds.sh)
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
 G1="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_WAVES"
 G2="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD"
