@@ -2881,7 +2881,8 @@ struct tspgpu_ctx {
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
     int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk: the best tour by array cell [ld], its direction and flag [2]
-    bool lp_broken = false;    // the grid did not come up co-resident once: keep to the one-launch-per-sweep path
+    int lp_skip = 0, lp_backoff = 16;   // the grid did not come up co-resident: the next lp_skip descents keep to the one-launch-per-sweep
+                                        // path, then it is tried again (16, 32, ... 1024 descents apart while it keeps failing)
     bool lp_used = false;      // the last descent ran in k_lds2opt
     bool lp_attr[4] = {false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
@@ -3622,7 +3623,8 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
     *ran = false;
     int E = 0, W = 0;
     size_t lds = 0;
-    if (ctx->lp_broken || !persist_fits(ctx, E, W, lds, tabu != nullptr)) return E_OK;
+    if (!persist_fits(ctx, E, W, lds, tabu != nullptr)) return E_OK;
+    if (ctx->lp_skip > 0) { ctx->lp_skip--; return E_OK; }
     if (!ctx->d_lp_slots) {
         HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));      // exchange slots, then the control words
         HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
@@ -3679,7 +3681,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
             const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(LP_BT), args, lds, ctx->stream);
             if (le != hipSuccess) {                    // (e.g. a device that does not grant 160 KiB of LDS to one workgroup)
                 (void)hipGetLastError();
-                if (first) { ctx->lp_broken = true; return E_OK; }
+                if (first) { ctx->lp_skip = 1 << 30; return E_OK; }      // (this device never grants the launch)
                 return fail(ctx, E_INTERNAL, "LDS-resident descent: launch failed: %s", hipGetErrorString(le));
             }
         }
@@ -3693,13 +3695,17 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
         if (status == LP_ST_NO_RENDEZVOUS) {
-            if (first) { ctx->lp_broken = true; return E_OK; }       // nothing written: the other path takes over
+            if (first) {                                               // nothing written: the other path takes over
+                ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
+                return E_OK;
+            }
             if (++retries > 3) return fail(ctx, E_INTERNAL, "LDS-resident descent: the grid of %d workgroups did not come up co-resident", W);
             continue;
         }
         if (status == LP_ST_LOST || status == LP_ST_RUNNING)
             return fail(ctx, E_INTERNAL, "LDS-resident descent: exchange lost (status %d after %d sweeps)", status, sd);
         first = false;
+        ctx->lp_backoff = 16;
         if (ctx->opt_timing && sd > 0) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -4135,7 +4141,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
-    case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_broken = false; break; // undocumented: rendezvous limit of k_lds2opt (tests)
+    case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_skip = 0; ctx->lp_backoff = 16; break; // undocumented: rendezvous limit of k_lds2opt (tests)
     case 98: // undocumented: per-workgroup phase stamps of the pipelined sweep (single tour)
         ctx->opt_stamps = value ? 1 : 0; drop_graphs(ctx);
         if (value && !ctx->d_stamps) HIP_TRY(hipMalloc(&ctx->d_stamps, (size_t)MAX_WGS_PER_TOUR * 64 * 8));
@@ -4144,7 +4150,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MATRIX_FREE: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad matrix-free mode"); ctx->opt_otf = (int)value; break;
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
-    case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_broken = false; break;
+    case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
     case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LP_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LP_EMAX); ctx->opt_persist_edges = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
     case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
