@@ -543,6 +543,37 @@ def main():
     if rank != 0:
         return
 
+    # ---- BASELINE config 2: fnl4461, NN(0) then iterated 2-opt to the local optimum (golden: 603 sweeps)
+    cfg2 = None
+    if aux and not args.no_sizes:
+        def cfg2_leg():
+            pts, _ = read_tsplib(os.path.join(DATA, "fnl4461.tsp"))
+            g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["instances"]["fnl4461"]["two_opt"]
+            e5 = T.Engine(local)
+            try:
+                e5.set_points(pts); e5.build_costs()
+                e5.tour_nn(0, 0)
+                ts = []
+                for _ in range(4):
+                    e5.tour_copy(1, 0); e5.tour_store(1, want_path=False)
+                    t1 = time.perf_counter()
+                    sw, _ = e5.tour_two_opt(1)
+                    ts.append(time.perf_counter() - t1)
+                p5, c5, _ = e5.tour_store(1)
+                info5 = e5.info()
+                m = len(pts)
+                dt5 = min(ts[1:])
+                return {"instance": "fnl4461", "n": m, "sweeps": int(sw), "ms_to_local_optimum": 1e3 * dt5, "us_per_sweep": 1e6 * dt5 / sw,
+                        "value": T.evals_per_sweep(m) * sw / dt5, "unit": "evals/s", "kernel": kernel_name(info5),
+                        "matrix_elem": NAMES[info5["elem"]], "block": info5["block"], "wgs_per_tour": info5["wgs_per_tour"],
+                        "roofline_frac": T.evals_per_sweep(m) * 2 * BYTES[info5["elem"]] / (dt5 / sw) / 1e9 / HBM_PEAK_GBS,
+                        "parity": {"golden": "tests/golden/golden.json fnl4461 two_opt (compiled reference)",
+                                   "ok": (int(sw), float(c5), fnv1a(p5)) == (g["sweeps"], g["final_cost"], g["final_fnv"]),
+                                   "sweeps": int(sw), "final_cost": float(c5)}}
+            finally:
+                e5.close()
+        cfg2 = guarded(cfg2_leg)
+
     # ---- mh_TabuSearch's walk (metaheuristic.c:86-245): k iterations from the 2-opt local optimum, LDS-resident and not
     tabu = None
     if aux and not args.no_sizes:
@@ -626,7 +657,7 @@ def main():
         "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
         "roofline": roof, "roofline_one_launch_per_sweep": roof_fused, "roofline_build": broof, "cpu_baseline": base,
         "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
-        "tabu_walk": tabu,
+        "tabu_walk": tabu, "config2_fnl4461": cfg2,
     }
     if base and "value" in base:
         out["gpu_over_cpu"] = out["value"] / base["value"]

@@ -3260,6 +3260,11 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         ctx->plan_lds = (size_t)(P + 1) * row + (size_t)((P + 2 + 3) & ~3) * 4 + 16 * sizeof(Partial) + 64;
     }
     if (kernel == 2) {
+        // a single uint16 tour past the resident kernel's size: two 16-byte vectors per thread on half as many threads
+        // (tools/tune_n4461.py: fnl4461 24.6 -> 18.2 us per sweep -- 9-wave workgroups fill the SIMDs unevenly --, n = 5000 /
+        // 6000 / 8192: 3-5 % faster; n = 16384 takes this shape anyway)
+        if (ctx->opt_block <= 0 && ctx->elem == TSPGPU_ELEM_U16 && ntours == 1 && nvec > 512)
+            BT = std::min(1024, std::max(256, ((nvec + 1) / 2 + 63) & ~63));
         nch = (nvec + BT - 1) / BT;
         while (nch > 4 && BT < 1024) { BT *= 2; nch = (nvec + BT - 1) / BT; }
         int inst = nch <= 1 ? 1 : nch <= 2 ? 2 : (nch == 3 && ctx->elem == TSPGPU_ELEM_U16) ? 3 : 4;
