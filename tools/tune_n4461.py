@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Launch shape of the streamed one-launch-per-sweep kernel for single uint16 tours past the resident kernel's size
+(fnl4461 = BASELINE config 2, n = 5000 / 6000 / 8192 uniform): microseconds per sweep for the automatic plan and for
+forced block sizes.  usage: python tools/tune_n4461.py"""
 import sys, time, os
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import travellingsalesmanoptimization_amd as T
 from bench import read_tsplib, reference_points
@@ -24,6 +28,6 @@ def bench(xy, label):
             except Exception as e:
                 print(f"{label} block={block}: {str(e)[:80]}")
     eng.close()
-bench(read_tsplib("/root/repo/tests/golden/data/fnl4461.tsp")[0], "fnl4461")
+bench(read_tsplib(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "data", "fnl4461.tsp"))[0], "fnl4461")
 for n in (5000, 6000, 8192):
     bench(reference_points(n, 123), f"n={n}")
