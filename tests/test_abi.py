@@ -55,6 +55,12 @@ def test_product_does_not_touch_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", ".cpp")) or f == "Makefile":
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower(), (dirpath, f)
+    # ... and no development tool imports it either (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do)
+    import re
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith(".py"):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
 
 
 def test_tsplib_reader_follows_the_reference_rules(tmp_path):
