@@ -51,11 +51,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 DATA = os.path.join(GOLDEN, "data")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
+LDS_PEAK_GBS = 256 * 256 * 2.4    # MI355X_MICROARCH.md LDS: ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s
+EXCHANGE_FLOOR_US = 2.74          # profiles/r02_slot_exchange_probe.txt: one 256-workgroup slot exchange on an idle chip
+
+_POINTS = {}
 
 
 def reference_points(n, seed):
     """src/tsp.c:468-476 + utils.h:23-26 on glibc: srand(seed); x,y = rand()/RAND_MAX*10000-5000.
-    Re-stated here (4 lines of libc calls) so that the product bench does not import the oracle."""
+    Re-stated here (4 lines of libc calls) so that the product bench does not import the oracle.
+    The process-wide rand() stream is also drawn from by the HIP runtime while it initialises, so main() draws every
+    point set it will need BEFORE the first GPU call (draw_points) and this function then only serves the cache."""
+    if (n, seed) in _POINTS:
+        return _POINTS[(n, seed)].copy()
+    assert not _POINTS.get("sealed"), f"point set ({n}, {seed}) requested after the first GPU call: add it to draw_points()"
     import ctypes
     libc = ctypes.CDLL(None)
     libc.srand(ctypes.c_uint(seed))
@@ -64,7 +73,15 @@ def reference_points(n, seed):
     for i in range(n):
         xy[i, 0] = (libc.rand() / RAND_MAX) * 10000 + (-5000)
         xy[i, 1] = (libc.rand() / RAND_MAX) * 10000 + (-5000)
-    return xy
+    _POINTS[(n, seed)] = xy
+    return xy.copy()
+
+
+def draw_points(sets):
+    """every uniform-random instance of the run, drawn before HIP is initialised; later requests must hit the cache"""
+    for n, seed in sets:
+        reference_points(n, seed)
+    _POINTS["sealed"] = True
 
 
 def read_tsplib(path):
@@ -228,6 +245,7 @@ def main():
         args.cpu_sweeps = 0
         args.batch_starts = 0
 
+    draw_points([(args.n, args.seed), (1024, 1), (16384, 123), (1024, 123), (3584, 123), (4096, 123)])
     import torch
     import torch.distributed as dist
     import travellingsalesmanoptimization_amd as T
@@ -238,10 +256,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
+        torch.cuda.set_device(local % max(torch.cuda.device_count(), 1))
+        # "nccl" = RCCL over xGMI; TSPGPU_BENCH_BACKEND=gloo rehearses the N > 1 branch on a box with fewer GPUs than ranks
+        # (collectives on CPU tensors, ranks sharing a device): tests/test_host_c.py
+        dist.init_process_group(os.environ.get("TSPGPU_BENCH_BACKEND", "nccl"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
+    backend = dist.get_backend() if world > 1 else None
+    local = local % max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local) if backend != "gloo" else torch.device("cpu")
     aux = rank == 0 and world == 1          # the auxiliary single-GPU legs
 
     ELEMS = {"auto": T.ELEM_AUTO, "u16": T.ELEM_U16, "i32": T.ELEM_I32, "f64": T.ELEM_F64}
@@ -250,12 +272,33 @@ def main():
     CTYPE = {T.ELEM_U16: "unsigned short", T.ELEM_I32: "int", T.ELEM_F64: "double"}
 
     def kernel_name(info):
+        if info.get("persist") and info.get("persist_window"):
+            return ("k_lds2opt_w (uint16 matrix resident in LDS as half-window rows in tour order, ONE launch per descent; "
+                    "kernel_ms_mean = launch duration / sweeps of the launch)")
         if info.get("persist"):
             return ("k_lds2opt (uint16 matrix resident in LDS in tour order, ONE launch per descent; "
                     "kernel_ms_mean = launch duration / sweeps of the launch)")
         if info.get("fused"):
             return "k_sweep_fused (sweep + apply of the previous move, one launch per sweep)"
         return {1: "k_sweep_simple", 2: "k_sweep_pipe", 3: "k_sweep_res", 4: "k_sweep_otf"}[info["kernel"]]
+
+    def phase_clocks(eng):
+        """the LDS-resident kernel's own phase clocks (option 98: wall_clock64 sums by thread 0 of every workgroup), one more
+        descent of slot 0's tour: mean over workgroups, us per sweep"""
+        eng.set_option(98, 1)
+        try:
+            eng.tour_copy(1, 0)
+            eng.tour_two_opt(1)
+            buf = np.zeros(1024 * 64, dtype=np.uint64)
+            eng.L.tspgpu_debug_stamps(eng.ctx, buf.ctypes.data, buf.size)
+        finally:
+            eng.set_option(98, 0)
+        st = buf.reshape(-1, 16)[:256, :9].astype(np.float64)
+        st = st[st[:, 8] > 0]
+        if not len(st):
+            return None
+        names = ["evaluation", "workgroup_reduction", "exchange", "reversal", "rows_fetched", "decode_and_swaps"]
+        return {nm: float((st[:, i] / st[:, 8]).mean() / 100.0) for i, nm in enumerate(names)}
 
     def timed_search(eng, evals):
         """the same search once more with HIP events on the engine's stream: around every batch of back-to-back
@@ -278,15 +321,32 @@ def main():
                "algorithmic_bytes_per_launch": evals * bpe, "bytes_per_eval": bpe, "evals_per_launch": evals,
                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
         if info.get("persist"):
-            # one launch runs the whole descent: the unit of the roofline is one SWEEP (= the work of one launch of the
-            # per-sweep kernels: n(n-3)/2 evaluations, 2 matrix cells each).  The cells come from LDS, not HBM: the
-            # fraction is the SURVEY 8d convention (algorithmic bytes / time / HBM peak), not a measure of HBM traffic.
-            out["unit_of_work"] = "sweep (launch duration / sweeps run by the launch)"
-            out["kernel_launches_timed"] = 1
-            out["sweeps_timed"] = launches
-            out["note"] = ("matrix cells are read from LDS (33.5 MB of the chip's 41.9 MB), HBM traffic per sweep is the rows "
-                           "re-fetched after a move (see traffic_from_committed_profile); bound in practice: the grid-wide "
-                           "exchange per sweep (DESIGN.md 4.7)")
+            # One launch runs the whole descent; the unit of work is one SWEEP (= the work of one launch of the per-sweep
+            # kernels: n(n-3)/2 evaluations, 2 matrix cells each).  The cells come from LDS, not HBM (PMC: ~1.2 MB of HBM
+            # traffic per sweep against 33.5 MB of algorithmic bytes), so this is NOT an HBM-bound kernel: what bounds a
+            # sweep is one grid-wide exchange (a fabric round trip all 256 workgroups wait for).  bound = "latency":
+            # achieved = us per sweep, peak = the measured floor of one exchange (tools/probes/slot_barrier_probe.hip),
+            # frac = floor / achieved.  SURVEY 8(d)'s convention (algorithmic bytes / time / 8 TB/s) is kept beside it as
+            # frac_nominal_hbm -- it can exceed what HBM could deliver and says nothing about HBM utilisation.
+            us = kernel_ms * 1e3
+            ph = guarded(phase_clocks, eng)
+            out.update({"bound": "latency", "achieved": us, "peak": EXCHANGE_FLOOR_US, "unit": "us per sweep (lower is better)",
+                        "frac": EXCHANGE_FLOOR_US / us,
+                        "exchange_floor_us": EXCHANGE_FLOOR_US,
+                        "exchange_floor_source": "profiles/r02_slot_exchange_probe.txt (256 workgroups, 16-byte records at 64-byte stride)",
+                        "phase_us": ph,
+                        "frac_nominal_hbm": achieved / HBM_PEAK_GBS, "achieved_nominal_hbm_GBs": achieved, "hbm_peak_GBs": HBM_PEAK_GBS,
+                        "unit_of_work": "sweep (launch duration / sweeps run by the launch)",
+                        "kernel_launches_timed": 1, "sweeps_timed": launches})
+            if isinstance(ph, dict) and ph.get("evaluation"):
+                # LDS bytes the evaluation reads per sweep = the algorithmic bytes (every pair: 2 cells of 2 bytes), over the
+                # evaluation phase alone, against the chip's ds_read_b128 rate
+                lds_gbs = evals * bpe / (ph["evaluation"] * 1e-6) / 1e9
+                out["lds_frac"] = lds_gbs / LDS_PEAK_GBS
+                out["lds_read_GBs_in_evaluation_phase"] = lds_gbs
+                out["lds_peak_GBs"] = LDS_PEAK_GBS
+            out["note"] = ("matrix cells are read from LDS; HBM traffic per sweep is the rows re-fetched after a move (see "
+                           "traffic_from_committed_profile); the sweep is bound by the grid-wide exchange (DESIGN.md 4.7)")
         return out
 
     def build_roofline(eng):
@@ -641,15 +701,17 @@ def main():
         "dtype": {T.ELEM_U16: "uint16 costs, int32 deltas", T.ELEM_I32: "int32", T.ELEM_F64: "f64"}[info["elem"]],
         "data": "synthetic",
         "config": {"workload": f"uniform-random EUC_2D n={n} (reference generator -n {n} -seed {seed}), "
-                               f"cost matrix resident in HBM, NN(start=rank) tour -> best-improvement 2-opt "
-                               f"to the local optimum; one step = one full local search",
+                               + ("cost matrix built in HBM and held in LDS (rows in tour order) for the whole descent, "
+                                  if info_main.get("persist") else "cost matrix resident in HBM, ")
+                               + "NN(start=rank) tour -> best-improvement 2-opt to the local optimum; one step = one full local search",
                    "n": n, "seed": seed, "evals_per_sweep": evals,
                    "sweeps_per_step_rank0": my_sweeps // max(args.steps, 1),
                    "matrix_elem": {T.ELEM_U16: "uint16 exact copy", T.ELEM_I32: "int32 exact copy", T.ELEM_F64: "f64"}[info["elem"]],
                    "sweep_kernel": info["kernel"], "wgs_per_tour": info["wgs_per_tour"],
                    "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
-                   "descent": ({"kernel": "k_lds2opt", "launches_per_descent": 1, "workgroups": info_main["persist_wgs"],
-                                "edges_per_workgroup": info_main["persist_edges"], "lds_bytes": info_main["persist_lds"], "block": 512}
+                   "descent": ({"kernel": "k_lds2opt_w" if info_main.get("persist_window") else "k_lds2opt", "launches_per_descent": 1,
+                                "workgroups": info_main["persist_wgs"], "edges_per_workgroup": info_main["persist_edges"],
+                                "lds_bytes": info_main["persist_lds"], "block": 1024 if info_main.get("persist_window") else 512}
                                if info_main.get("persist") else {"kernel": "one launch per sweep"}),
                    "parallelism": f"multistart-shard{world}"},
         "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,

@@ -67,11 +67,16 @@ enum {
                                    the neighbour lists */
     TSPGPU_OPT_SWEEP_CAP = 13,  /* sweeps per start in tspgpu_multistart_nn_2opt (-1 = to the local optimum, the
                                    reference's behaviour; >= 0 caps every local search: tests and bounded runs) */
-    TSPGPU_OPT_PERSIST = 16,    /* single-tour descent with the whole uint16 matrix resident in LDS, one launch per descent
-                                   (n <= 4096, one workgroup per CU), and tspgpu_tabu_search's walk the same way (n up to
-                                   about 3800): 0 never, 1 (default) where it applies -- falls back to one launch per sweep
-                                   when the grid cannot be co-resident --, 2 or fail with code 8 */
-    TSPGPU_OPT_PERSIST_EDGES = 17 /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16) */
+    TSPGPU_OPT_PERSIST = 16,    /* single-tour descent with the uint16 matrix resident in LDS, one launch per descent
+                                   (whole rows for n <= 4096, half-window rows up to n of about 5400, one workgroup per CU),
+                                   and tspgpu_tabu_search's walk the same way (n up to about 3800): 0 never, 1 (default)
+                                   where it applies -- falls back to one launch per sweep when the grid cannot be
+                                   co-resident --, 2 or fail with code 8 */
+    TSPGPU_OPT_PERSIST_EDGES = 17, /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16 with whole
+                                   rows, 24 with half-window rows) */
+    TSPGPU_OPT_PERSIST_WINDOW = 18 /* rows of that kernel: 0 auto (whole rows where they fit the chip's LDS, else the half
+                                   window of n/2 cells ahead of the workgroup's own edges), 1 half-window rows wherever they
+                                   apply, 2 whole rows only */
 };
 
 int  tspgpu_device_count(void);
@@ -85,7 +90,9 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * 10 matrix-free mode in use, 11 one-launch-per-sweep path in use, 12 cells per side of the NN grid (0: the
  * grid kernel is not in use), 13 most points in one grid cell, 14 the fused streaming kernel takes two edges per
  * barrier interval, 15 the last single-tour descent ran LDS-resident (TSPGPU_OPT_PERSIST), 16 / 17 / 18 workgroups, tour
- * edges per workgroup and LDS bytes per workgroup of that kernel on this instance (0: it does not apply) */
+ * edges per workgroup and LDS bytes per workgroup of that kernel on this instance (0: it does not apply), 19 window cells per
+ * row of its half-window form (0: whole rows), 20 the last single-tour descent ran in the half-window form, 21 the last
+ * single-tour descent began LDS-resident and was finished one launch per sweep (the grid lost its co-residency) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

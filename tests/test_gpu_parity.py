@@ -1227,3 +1227,146 @@ def test_lds_resident_size_sweep(eng, T, O, n, persist):
     assert eng.info()["persist"] == (1 if fits_tabu else 0)
     obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
     assert np.array_equal(trace, otrace) and final == ofinal and np.array_equal(g, oseed) and np.array_equal(best, obest), n
+
+
+# ------------------------------------------------------------------ the half-window LDS-resident descent (k_lds2opt_w)
+@pytest.fixture
+def window(eng, T):
+    """TSPGPU_OPT_PERSIST = 2 + TSPGPU_OPT_PERSIST_WINDOW = 1: the single-tour descent must run in k_lds2opt_w"""
+    eng.set_option(T.OPT_PERSIST, 2); eng.set_option(T.OPT_PERSIST_WINDOW, 1)
+    yield
+    eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_EDGES, 0); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
+
+
+def _descent_against_oracle(eng, O, c, succ0, cost0, sweeps_cap):
+    """one launch of at most sweeps_cap sweeps against as many ref_2opt_once calls of the oracle, move by move"""
+    eng.set_option(5, 8192)                          # TSPGPU_OPT_HISTORY
+    try:
+        eng.tour_load(0, succ0)
+        sw, rc = eng.tour_two_opt(0, max_sweeps=sweeps_cap)
+        a, b, d = eng.history(8192)
+        got, gcost, _ = eng.tour_store(0)
+    finally:
+        eng.set_option(5, 0)
+    succ, cost = succ0.copy(), cost0
+    for i in range(sw):
+        dd, cost, mv = O.two_opt_once(c, succ, cost)
+        want = (mv[0], mv[1], dd) if dd < -1e-7 else (-1, -1, float(d[i]))
+        assert (int(a[i]), int(b[i]), float(d[i])) == want, (i, mv, dd, a[i], b[i], d[i])
+    assert rc == 0 and gcost == cost and np.array_equal(got, succ)
+    return sw
+
+
+@pytest.mark.parametrize("edges", [0, 3, 16, 24])
+@pytest.mark.parametrize("name", ["kroA100", "n200_s3", "pr1002", "n1000_s123", "n1024_s1"])
+def test_lds_window_to_local_optimum_golden(eng, T, O, instances, golden, name, edges, window):
+    """the half-window kernel forced onto small instances (1 .. 24 edges per workgroup, packed 16-bit and 32-bit deltas,
+    n % 8 != 0): golden sweep count, final cost, tour and every recorded move of the descent"""
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST_EDGES, edges)
+    if eng.info()["persist_window_cells"] == 0:
+        pytest.skip("the window of this many edges does not fit n")
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    succ, nn_cost = O.nn_tour(c, 0)
+    sw = _descent_against_oracle(eng, O, c, succ, nn_cost, -1)
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+    got, gcost, _ = eng.tour_store(0)
+    assert (sw, gcost, fx(O, got)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+
+
+def test_lds_window_fnl4461_config3(eng, T, O, golden):
+    """BASELINE config 3 on the path it now takes by default: fnl4461 (n = 4461 > 4096: the matrix does not fit the
+    chip's LDS, its half windows do) NN(0) -> local optimum in ONE launch: 603 sweeps, 192601, the golden tour and the
+    per-sweep cost trace of the compiled reference"""
+    xy, _ = O.read_tsplib(data_path("fnl4461"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    g = golden["instances"]["fnl4461"]["two_opt"]
+    succ, nn_cost = eng.nn_tour(0)
+    assert nn_cost == g["nn_cost"] and fx(O, succ) == g["nn_fnv"]
+    eng.set_option(T.OPT_HISTORY, 4096)
+    try:
+        cost, sweeps, rc = eng.two_opt(succ)
+        info = eng.info()
+        assert rc == 0 and info["persist"] == 1 and info["persist_window"] == 1 and info["persist_window_cells"] > 0
+        assert (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+        assert O.valid_tour(succ)
+        a, b, d = eng.history(4096)
+        assert len(a) == sweeps and a[-1] == -1
+        run = nn_cost
+        for i, want in enumerate(g["trace"]):
+            run += d[i]
+            assert run == want
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0)
+
+
+@pytest.mark.parametrize("n", [64, 97, 200, 513, 1000, 2047, 3000, 4096, 4097, 4461, 5000, 5376, 5400])
+def test_lds_window_size_sweep(eng, T, O, n, window):
+    """sizes around the half-window kernel's geometry (odd n, n % 8, the largest n whose windows fit the LDS with two
+    staging rows / with one): 30 sweeps in one launch against the oracle, move by move"""
+    xy = O.random_points(n, 2000 + n)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    assert eng.info()["persist_window_cells"] > 0, eng.info()
+    succ, cost = O.nn_tour(c, n // 3)
+    sw = _descent_against_oracle(eng, O, c, succ, cost, 30)
+    assert sw == 30 or sw < 30
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+
+
+def test_lds_window_falls_back_past_its_limit(eng, T, O):
+    """n = 5800: not even the half windows fit -- the descent runs one launch per sweep (and says so); asking for the
+    resident kernel explicitly fails loudly"""
+    n = 5800
+    xy = O.random_points(n, 7)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_PERSIST, 1)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, 0)
+    eng.tour_load(0, succ)
+    sw, rc = eng.tour_two_opt(0, max_sweeps=5)
+    assert (sw, rc) == (5, 0) and eng.info()["persist"] == 0
+    for _ in range(5):
+        d, cost, _ = O.two_opt_once(c, succ, cost)
+    got, gcost, _ = eng.tour_store(0)
+    assert gcost == cost and np.array_equal(got, succ)
+    eng.set_option(T.OPT_PERSIST, 2)
+    try:
+        with pytest.raises(Exception) as ei:
+            eng.tour_two_opt(0, max_sweeps=1)
+        assert ei.value.code == 8
+    finally:
+        eng.set_option(T.OPT_PERSIST, 1)
+
+
+def test_lds_resident_hands_over_mid_descent(T, O, instances, golden):
+    """a deadline-bounded descent relaunches k_lds2opt per sweep budget; when a LATER launch no longer gets
+    the whole chip (test hook 96 makes the 2nd launch fail its rendezvous, as another context holding CUs would) the rest
+    of the descent (after three more tries) runs one launch per sweep from the tour the last launch wrote back -- one state: valid tour, its cost,
+    the sweep count = the history's length, every move the oracle's"""
+    e = T.Engine(0)
+    try:
+        xy, c = instances("n1000_s123")
+        e.set_option(T.OPT_ELEM, 3); e.set_points(xy); e.build_costs()
+        succ0, cost0 = O.nn_tour(c, 0)
+        e.set_option(T.OPT_HISTORY, 4096)
+        e.set_option(96, 4)                                      # the 2nd .. 5th launch fail: more than the 3 retries
+        g = succ0.copy()
+        gcost, sweeps, rc = e.two_opt(g, time_left_s=0.004)     # first launch: a budget of 0.004 / 3 / 8 us = 166 of the 168 sweeps
+        a, b, d = e.history(4096)
+        assert e.info()["persist_handed"] == 1 and e.info()["persist"] == 0
+        assert rc in (0, 4) and sweeps >= 166 and len(a) == sweeps
+        assert O.valid_tour(g) and O.tour_cost(c, g) == gcost and cost0 + d.sum() == gcost
+        succ, cost = succ0.copy(), cost0
+        for i in range(sweeps):
+            dd, cost, mv = O.two_opt_once(c, succ, cost)
+            if dd < -1e-7:
+                assert (a[i], b[i], d[i]) == (mv[0], mv[1], dd), i
+        assert np.array_equal(g, succ)
+        if rc == 0:
+            gg = golden["random"]["n1000_s123"]["two_opt"]
+            assert (sweeps, gcost) == (gg["sweeps"], gg["final_cost"])
+    finally:
+        e.close()

@@ -201,7 +201,16 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] == "GB/s"
+    # the headline descent runs LDS-resident (one launch): what bounds a sweep is the grid-wide exchange, and the line says so
+    assert r["bound"] == "latency" and r["peak"] == r["exchange_floor_us"] and abs(r["frac"] - r["peak"] / r["achieved"]) < 1e-9
+    assert abs(r["achieved"] - 1e3 * r["kernel_ms_mean"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(r["frac_nominal_hbm"] - r["achieved_nominal_hbm_GBs"] / 8000.0) < 1e-9      # SURVEY 8(d)'s convention, kept beside it
+    assert abs(r["achieved_nominal_hbm_GBs"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms_mean"] * 1e-3) / 1e9) < 1e-6
+    ph = r["phase_us"]
+    assert set(ph) == {"evaluation", "workgroup_reduction", "exchange", "reversal", "rows_fetched", "decode_and_swaps"}
+    assert 0.5 * r["achieved"] < sum(ph.values()) < 1.5 * r["achieved"] and ph["exchange"] > ph["evaluation"] > 0
+    assert 0 < r["lds_frac"] < 1
+    assert "held in LDS" in d["config"]["workload"] and "resident in HBM" not in d["config"]["workload"]
     assert d["final_cost_rank0"] == 488522.0 and d["config"]["sweeps_per_step_rank0"] == 609
     assert d["parity"]["ok"] is True and d["parity"]["final_fnv"]          # the in-run gate against the committed golden
     assert r["traffic"] is None and "traffic_from_committed_profile" in r   # PMC bytes are not measured by the run itself
@@ -211,11 +220,43 @@ def test_bench_line_contract():
         assert k in d
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
-    # the headline descent runs LDS-resident (one launch); the per-sweep kernel is reported beside it
     assert d["config"]["descent"]["kernel"] == "k_lds2opt" and d["config"]["descent"]["workgroups"] == 256
     assert r["kernel"].startswith("k_lds2opt") and r["sweeps_timed"] == 609 and r["kernel_launches_timed"] == 1
+    # the streamed one-launch-per-sweep kernel on the same workload IS HBM-bound (PMC traffic ~ algorithmic bytes): bound "hbm"
     f = d["roofline_one_launch_per_sweep"]
+    assert f["bound"] == "hbm" and f["peak"] == 8000.0 and abs(f["frac"] - f["achieved"] / f["peak"]) < 1e-9 and f["unit"] == "GB/s"
     assert f["kernel"].startswith("k_sweep_fused") and f["kernel_launches_timed"] >= 576 and f["kernel_ms_mean"] > r["kernel_ms_mean"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_gloo_on_one_gpu():
+    """the N > 1 branch of bench.py (torch.distributed launch, barrier, per-step exchange, MAX over ranks,
+    SUM of sweeps, rank 0's host_c_path leg) rehearsed as two gloo ranks sharing device 0 -- collectives on CPU tensors,
+    TSPGPU_BENCH_BACKEND=gloo -- so that the driver's first multi-GPU run cannot die on an untested branch.  No scaling
+    number is taken from this (two processes on one GPU)."""
+    import json, subprocess, sys, socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, TSPGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--n", "1024", "--seed", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "multistart-shard2"
+    assert d["parity"]["ok"] is True                         # rank 0 searched from NN(0): the golden of n1024_s1
+    ev = 1024 * 1021 // 2
+    tot = d["value"] * d["ms_per_step"] * 1e-3 * d["steps"] / ev        # sweeps summed over both ranks
+    assert abs(tot - round(tot)) < 1e-3 and round(tot) >= 2 * 2 * 100   # two ranks x two steps x (> 100 sweeps each)
+    assert d["config"]["sweeps_per_step_rank0"] == 174
+    hc = d["host_c_path"]
+    assert hc["devices"] == 1 and hc["pr1002_all_starts"]["golden_cost_266290"] is True
 
 
 def _mod_costs_matrix(c, seed):

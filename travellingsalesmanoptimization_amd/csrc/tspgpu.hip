@@ -2810,6 +2810,7 @@ __global__ void k_cap_now(Tours S, int slot0, int count)
 }
 
 #include "tspgpu_lds2opt.inc"
+#include "tspgpu_lds2opt_win.inc"
 
 // ===========================================================================
 // host side
@@ -2878,7 +2879,12 @@ struct tspgpu_ctx {
     // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
     int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
+    int opt_persist_window = 0; // 0 auto (half-window rows where whole rows do not fit the chip's LDS), 1 always, 2 never
+    bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
+    bool lp_handed = false;    // run_persist began a descent and handed the rest to the per-sweep path
+    bool lpw_attr[2] = {false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
+    int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
     int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk: the best tour by array cell [ld], its direction and flag [2]
     int lp_skip = 0, lp_backoff = 16;   // the grid did not come up co-resident: the next lp_skip descents keep to the one-launch-per-sweep
@@ -3615,7 +3621,28 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, boo
     lds = (size_t)(e + 1) * nl * 2 + nl * 4 + std::max<size_t>(nl * 2, 256) + (tabu ? nl * 2 : 0);   // (+ the nodes' ages)
     if (lds > ctx->lds_max) return false;
     E = e; W = (n + e - 1) / e;
-    return W <= ctx->cus && W <= LP_BT;
+    return W <= ctx->cus && W <= 256;        // (the exchange keeps two candidate sets of 4 polling waves: 256 slots)
+}
+
+// The half-window form (k_lds2opt_w): every row kept as the window of E + n/2 + 16.. cells ahead of the workgroup's first own
+// cell, so that instances a little past n = 4096 (fnl4461, BASELINE config 3) stay LDS-resident.  Plain 2-opt only.
+static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, int &Ws, int &nstage)
+{
+    const int n = ctx->n;
+    if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 64 || n > 8191) return false;
+    int e = (n + std::min(ctx->cus, 256) - 1) / std::min(ctx->cus, 256);
+    if (ctx->opt_persist_edges > e) e = ctx->opt_persist_edges;
+    if (e > LW_EMAX) return false;
+    const int ws = (e + n / 2 + 23) & ~7;             // window cells per row (see k_lds2opt_w)
+    if (ws > n || (ws >> 3) - 1 > LW_BT) return false;
+    const size_t nl = (size_t)((n + 7) & ~7);
+    if ((nl >> 3) > (size_t)LW_BT) return false;
+    const size_t fixed = (size_t)(e + 1) * ws * 2 + (nl + 8) * 4 + 512;
+    int ns = 2;
+    if (fixed + 2 * nl * 2 > ctx->lds_max) ns = 1;
+    if (fixed + (size_t)ns * nl * 2 > ctx->lds_max) return false;
+    E = e; W = (n + e - 1) / e; Ws = ws; nstage = ns; lds = fixed + (size_t)ns * nl * 2;
+    return W <= ctx->cus && W <= 256;
 }
 
 // *ran = false: nothing was touched (does not apply, or the grid did not come up co-resident): the caller takes the
@@ -3623,12 +3650,21 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, boo
 // every launch leaves a consistent tour (the sweep that ran is applied, refinment.c:17-26).
 struct PersistTabu { int k, tenure, t_min, t_max, up; double best; };
 
-static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *deadline_hit, bool *ran, const PersistTabu *tabu = nullptr)
+// *time_left_io: the deadline budget; when the descent has to be handed to the one-launch-per-sweep path half way (the grid
+// lost its co-residency after the first launch: another context took CUs) it holds the time that is left and *ran stays
+// false -- the slot holds the consistent tour the last completed launch wrote back, the caller continues from there.
+static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *deadline_hit, bool *ran, const PersistTabu *tabu = nullptr)
 {
     *ran = false;
-    int E = 0, W = 0;
+    const double time_left_s = time_left_io ? *time_left_io : -1.0;
+    int E = 0, W = 0, Ws = 0, nstage = 0;
     size_t lds = 0;
-    if (!persist_fits(ctx, E, W, lds, tabu != nullptr)) return E_OK;
+    bool win = false;
+    if (ctx->opt_persist_window == 1 && !tabu && persist_fits_w(ctx, E, W, lds, Ws, nstage)) win = true;
+    else if (!persist_fits(ctx, E, W, lds, tabu != nullptr)) {
+        if (tabu || ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, nstage)) return E_OK;
+        win = true;
+    }
     if (ctx->lp_skip > 0) { ctx->lp_skip--; return E_OK; }
     if (!ctx->d_lp_slots) {
         HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));      // exchange slots, then the control words
@@ -3641,17 +3677,27 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         ctx->lp_best_n = ctx->ld;
     }
     const int pk = (tabu ? ctx->max8k : ctx->max16k) ? 1 : 0;
-    const void *fn = tabu ? (pk ? (const void *)k_lds2opt<true, true> : (const void *)k_lds2opt<false, true>)
+    const void *fn = win ? (pk ? (const void *)k_lds2opt_w<true> : (const void *)k_lds2opt_w<false>)
+                   : tabu ? (pk ? (const void *)k_lds2opt<true, true> : (const void *)k_lds2opt<false, true>)
                           : (pk ? (const void *)k_lds2opt<true, false> : (const void *)k_lds2opt<false, false>);
-    if (!ctx->lp_attr[pk + (tabu ? 2 : 0)]) {
+    bool &attr = win ? ctx->lpw_attr[pk] : ctx->lp_attr[pk + (tabu ? 2 : 0)];
+    if (!attr) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
-        ctx->lp_attr[pk + (tabu ? 2 : 0)] = true;
+        attr = true;
     }
+    const int block = win ? LW_BT : LP_BT;
     const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
-    if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; *ran = true; ctx->lp_used = true; return E_OK; }
+    if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; *ran = true; ctx->lp_used = true; ctx->lp_window = win; return E_OK; }
     double sweep_s = 8e-6;
     bool first = true, late = false;
     int retries = 0;
+    // hand the rest of the descent to the per-sweep path (nothing of this launch was written: the slot is consistent)
+    auto hand_over = [&]() {
+        ctx->lp_handed = !first;
+        ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
+        if (time_left_io && t_end >= 0) *time_left_io = std::max(0.0, t_end - now_s());
+        return E_OK;
+    };
     for (;;) {
         int budget = -1;
         if (t_end >= 0) {
@@ -3665,9 +3711,10 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
         PersistArgs A;
         memset(&A, 0, sizeof A);
         A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
-        A.E = E; A.nl = (ctx->n + 7) & ~7; A.budget = budget;
+        A.E = E; A.nl = (ctx->n + 7) & ~7; A.budget = budget; A.Ws = Ws; A.nstage = nstage;
         A.slots = ctx->d_lp_slots; A.ctl = d_ctl; A.hist = ctx->hist;
         A.hello_ticks = ctx->opt_lp_hello;   // 2 ms (test hook 97: negative = workgroup 0 withholds its record for that long)
+        if (ctx->opt_lp_fail_at > 0 && !first) { ctx->opt_lp_fail_at--; A.hello_ticks = -5000; }   // test hook 96: the next N relaunches fail their rendezvous
         A.spin_ticks = 100000000;      // 1 s
         A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
         if (tabu) {
@@ -3683,7 +3730,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
             HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         }
         {
-            const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(LP_BT), args, lds, ctx->stream);
+            const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(block), args, lds, ctx->stream);
             if (le != hipSuccess) {                    // (e.g. a device that does not grant 160 KiB of LDS to one workgroup)
                 (void)hipGetLastError();
                 if (first) { ctx->lp_skip = 1 << 30; return E_OK; }      // (this device never grants the launch)
@@ -3704,11 +3751,16 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
                 ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
                 return E_OK;
             }
-            if (++retries > 3) return fail(ctx, E_INTERNAL, "LDS-resident descent: the grid of %d workgroups did not come up co-resident", W);
+            if (++retries > 3) return hand_over();     // another context holds CUs: the per-sweep path finishes the descent
             continue;
         }
-        if (status == LP_ST_LOST || status == LP_ST_RUNNING)
-            return fail(ctx, E_INTERNAL, "LDS-resident descent: exchange lost (status %d after %d sweeps)", status, sd);
+        if (status == LP_ST_LOST) {
+            // an exchange timed out mid-launch (the grid is no longer co-resident): nothing of this launch was written
+            if (tabu && !first) return fail(ctx, E_INTERNAL, "LDS-resident tabu walk: exchange lost after %d iterations", sd);
+            return hand_over();
+        }
+        if (status == LP_ST_RUNNING)
+            return fail(ctx, E_INTERNAL, "LDS-resident descent: no status written (after %d sweeps)", sd);
         first = false;
         ctx->lp_backoff = 16;
         if (ctx->opt_timing && sd > 0) {
@@ -3722,12 +3774,21 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double time_left_s, bool *dead
     if (late && deadline_hit) *deadline_hit = true;
     *ran = true;
     ctx->lp_used = true;
+    ctx->lp_window = win;
     return E_OK;
 }
 
 // Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
 // done, `max_iters` pairs were issued (tabu), or the deadline passed (checked before every batch; the batches
 // shrink to single iterations once fewer than three batches' worth of time is left, refinment.c:17-24).
+__global__ void k_rebase(Tours S, int slot, int delta)     // sweep counter and cap of a slot shifted by delta (see run_sweeps)
+{
+    S.nsweeps[slot] += delta;
+    if (S.cap_sweeps[slot] >= 0) S.cap_sweeps[slot] += delta;
+}
+
+static int run_sweeps_plain(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s, bool *deadline_hit);
+
 static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s,
                       bool *deadline_hit)
 {
@@ -3744,11 +3805,36 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
     // (an explicit kernel or launch-structure choice -- TSPGPU_OPT_KERNEL / _FUSED -- keeps to that choice)
     if (!tabu && ntours == 1 && (ctx->opt_persist == 2 || (ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1))) {
         bool ran = false;
-        const int rc = run_persist(ctx, slot0, time_left_s, deadline_hit, &ran);
+        ctx->lp_handed = false;
+        const int rc = run_persist(ctx, slot0, &time_left_s, deadline_hit, &ran);     // (half way handed over: time_left_s = what is left)
         if (rc) return rc;
         if (ran) return E_OK;
-        if (ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident descent does not apply (uint16 cells, n in [64, 4096], one idle chip)");
+        if (ctx->lp_handed) {
+            // The LDS-resident kernel began this descent and lost its grid (another context took CUs): the slot holds the
+            // tour its last completed launch wrote back.  The per-sweep kernels count their sweeps from 0: run them on a
+            // rebased counter / cap / history and shift everything back afterwards.
+            int base = 0;
+            HIP_TRY(hipMemcpyAsync(&base, ctx->S.nsweeps + slot0, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            const HistBuf keep = ctx->hist;
+            const int hb = std::min(base, keep.cap);
+            if (keep.cap > 0) { ctx->hist.a += hb; ctx->hist.b += hb; ctx->hist.d += hb; ctx->hist.cap -= hb; }
+            drop_graphs(ctx);
+            hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, -base);
+            int rc2 = run_sweeps_plain(ctx, slot0, 1, false, max_iters, time_left_s, deadline_hit);
+            hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, base);
+            if (!rc2 && hipGetLastError() != hipSuccess) rc2 = fail(ctx, E_INTERNAL, "k_rebase launch failed");
+            ctx->hist = keep;
+            drop_graphs(ctx);
+            return rc2;
+        }
+        if (ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident descent does not apply (uint16 cells, n in [64, ~5400], one idle chip)");
     }
+    return run_sweeps_plain(ctx, slot0, ntours, tabu, max_iters, time_left_s, deadline_hit);
+}
+
+static int run_sweeps_plain(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s, bool *deadline_hit)
+{
     if (!tabu && ctx->symmetric && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2) &&
         (ctx->opt_fused == 2 || (ctx->opt_fused == 1 && ntours <= 4)))
         return run_fused(ctx, slot0, ntours, time_left_s, deadline_hit);
@@ -4146,6 +4232,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 96: ctx->opt_lp_fail_at = (int)value; break; // undocumented: see opt_lp_fail_at (tests)
     case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_skip = 0; ctx->lp_backoff = 16; break; // undocumented: rendezvous limit of k_lds2opt (tests)
     case 98: // undocumented: per-workgroup phase stamps of the pipelined sweep (single tour)
         ctx->opt_stamps = value ? 1 : 0; drop_graphs(ctx);
@@ -4156,7 +4243,8 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
-    case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LP_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LP_EMAX); ctx->opt_persist_edges = (int)value; break;
+    case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LW_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LW_EMAX); ctx->opt_persist_edges = (int)value; break;
+    case TSPGPU_OPT_PERSIST_WINDOW: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad window mode"); ctx->opt_persist_window = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
     case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
     case TSPGPU_OPT_SWEEP_CAP: if (value < -1 || value > INT_MAX) return fail(ctx, E_INVALID, "bad sweep cap"); ctx->opt_sweep_cap = (int)value; break;
@@ -4183,11 +4271,17 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 11: return (ctx->symmetric && ctx->opt_fused && fused_kernel(ctx->elem, ctx->plan_NCH, ctx->plan_kernel, ctx->plan_pipe2)) ? 1 : 0;
     case 14: return (ctx->plan_pipe2 || ctx->plan_pipe2_sweep) ? 1 : 0;
     case 15: return ctx->lp_used ? 1 : 0;
-    case 16: case 17: case 18: {             // geometry of the LDS-resident descent (0: it does not apply to the instance)
-        int E = 0, W = 0; size_t lds = 0;
-        if (!persist_fits(ctx, E, W, lds)) return 0;
-        return what == 16 ? W : what == 17 ? E : (long)lds;
+    case 16: case 17: case 18: case 19: {    // geometry of the LDS-resident descent (0: it does not apply to the instance)
+        int E = 0, W = 0, Ws = 0, ns = 0; size_t lds = 0;
+        const bool full = ctx->opt_persist_window != 1 && persist_fits(ctx, E, W, lds);
+        if (!full && (ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, ns))) {
+            if (!persist_fits(ctx, E, W, lds)) return 0;
+            Ws = 0;
+        }
+        return what == 16 ? W : what == 17 ? E : what == 18 ? (long)lds : Ws;
     }
+    case 20: return ctx->lp_used && ctx->lp_window ? 1 : 0;
+    case 21: return ctx->lp_handed ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
@@ -4534,7 +4628,7 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
     if (k > 0 && ctx->symmetric && (ctx->opt_persist == 2 || (ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1))) {
         // the whole walk in one launch, matrix and ages in LDS (k_lds2opt<., true>) where it applies
         const PersistTabu pt = {k, tenure, t_min, t_max, up, *cost};
-        if ((rc = run_persist(ctx, 0, -1, nullptr, &ran, &pt))) return rc;
+        if ((rc = run_persist(ctx, 0, nullptr, nullptr, &ran, &pt))) return rc;
         if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident tabu walk does not apply (uint16 cells, n in [64, ~3800], one idle chip)");
     }
     if (k > 0 && !ran && (rc = run_sweeps(ctx, 0, 1, true, k, -1, nullptr))) return rc;

@@ -107,7 +107,7 @@ static bool past_deadline(void)
  * the contents (cplex_model.c:1176-1258 refills one buffer per callback), so nothing is cached across calls. */
 static tspgpu_ctx *ctx_for(double *costs)
 {
-    if (costs == tsp_inst.costs) return tsp_gpu();
+    if (costs == tsp_inst.costs || (!costs && tsp_lazy_costs)) return tsp_gpu();
     tspgpu_ctx *g = thread_gpu();
     if (!g) return NULL;
     if (tspgpu_set_costs(g, costs, tsp_inst.nnodes) != 0) {
@@ -145,7 +145,7 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
         /* the reference recomputes the cost and leaves at the first poll */
         double c = 0;
         for (int i = 0; i < tsp_inst.nnodes; i++)
-            c += costs ? costs[(size_t)i * tsp_inst.nnodes + solution->path[i]] : tsp_get_cost(i, solution->path[i]);
+            c += costs ? costs[(size_t)i * tsp_inst.nnodes + solution->path[i]] : tsp_get_cost(i, solution->path[i]);   /* (a lazy host copy: tsp_get_cost) */
         solution->cost = c;
         log_debug("time limit exceeded in 2opt");
         e = DEADLINE_EXCEEDED;
@@ -164,14 +164,16 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
     return e;
 }
 
-/* refinment.c:39-93 */
+/* refinment.c:39-93.  The return value is the best delta and has no room for an error: a device failure here is fatal
+ * (log_fatal + tsp_handlefatal, what the reference does with errors it cannot return, tsp.c:738-742) -- returning 0
+ * would make a caller that loops on the delta stop as if it had reached a local optimum. */
 double ref_2opt_once(tsp_solution *solution, double *costs)
 {
     tspgpu_ctx *g = ctx_for(costs);
     double delta = 0;
     if (!g || tspgpu_two_opt_once(g, solution->path, &solution->cost, &delta) != 0) {
-        log_error("tspgpu_two_opt_once failed: %s", g ? tspgpu_last_error(g) : "no device");
-        return 0; /* "no improving move": callers stop looping */
+        log_fatal("tspgpu_two_opt_once failed: %s", g ? tspgpu_last_error(g) : "no device");
+        tsp_handlefatal();
     }
     return delta;
 }
@@ -195,7 +197,7 @@ void ref_reverse_path(int a, int succ_a, int b, int succ_b, int *prev, int *path
 /* heuristics.c:216-288 */
 ERROR_CODE h_greedyutil(int starting_node, tsp_solution *solution, double *costs)
 {
-    if (!costs && !tsp_matrix_free) { log_error("matrix of costs not found"); return INTERNAL; }
+    if (!costs && !tsp_matrix_free && !tsp_lazy_costs) { log_error("matrix of costs not found"); return INTERNAL; }
     if (starting_node >= tsp_inst.nnodes || starting_node < 0) { log_error("starting node not correct"); return UNAVAILABLE; }
     if (past_deadline()) { log_warn("time limit exceeded in greedy util"); return DEADLINE_EXCEEDED; }
     tspgpu_ctx *g = ctx_for(costs);

@@ -16,6 +16,12 @@ instance tsp_inst;
 options tsp_env;
 int tsp_edge_weight_kind = TSPGPU_EUC_2D;
 bool tsp_matrix_free = false;
+/* tsp_inst.costs on the host only when somebody reads it: the heuristic path never does (every O(n^2) loop runs on the
+ * device), and downloading n x n doubles (2.74 GB for d18512) costs seconds before the clock even starts.  Off by
+ * default -- code that indexes tsp_inst.costs directly (the reference's CPLEX path) finds it filled as before --;
+ * the `tsp` executable, which only runs the heuristic path, turns it on (TSP_EAGER_COSTS=1 turns it off again).
+ * With it on, tsp_inst.costs stays NULL until tsp_get_cost / tsp_host_costs() materialise it. */
+bool tsp_lazy_costs = false;
 
 static struct tspgpu_ctx *g_ctx = NULL;
 static struct tspgpu_multi *g_multi = NULL;    /* set when TSP_GPU_DEVICES names the devices; owns g_ctx then */
@@ -27,15 +33,19 @@ static int device_list(int *out, int cap)
     const char *s = getenv("TSP_GPU_DEVICES");
     int k = 0;
     if (!s) return 0;
-    while (*s && k < cap) {
+    while (*s == ' ') s++;
+    for (;;) {
         char *end;
         const long v = strtol(s, &end, 10);
-        if (end == s) break;
+        if (end == s || v < 0 || v > 1023 || k >= cap) return -1;      /* "", "a,b", "0,,1", "-1": malformed */
         out[k++] = (int)v;
         s = end;
-        while (*s == ',' || *s == ' ') s++;
+        while (*s == ' ') s++;
+        if (!*s) return k;
+        if (*s != ',') return -1;
+        s++;
+        while (*s == ' ') s++;
     }
-    return k;
 }
 
 struct tspgpu_ctx *tsp_gpu(void)
@@ -43,6 +53,10 @@ struct tspgpu_ctx *tsp_gpu(void)
     if (!g_ctx) {
         int devs[64];
         const int nd = device_list(devs, 64);
+        if (nd < 0) {      /* a typo must not silently turn an 8-GPU run into a 1-GPU run */
+            log_fatal("TSP_GPU_DEVICES=\"%s\" is not a comma-separated list of device ids", getenv("TSP_GPU_DEVICES"));
+            return NULL;
+        }
         if (nd > 0) {
             int rc = tspgpu_multi_create(devs, nd, &g_multi);
             if (rc != 0) {
@@ -50,7 +64,12 @@ struct tspgpu_ctx *tsp_gpu(void)
                 g_multi = NULL;
                 return NULL;
             }
-            const char *ex = getenv("TSP_GPU_EXCHANGE");     /* "rccl" | "host"; unset = automatic */
+            const char *ex = getenv("TSP_GPU_EXCHANGE");     /* "rccl" | "host" | "auto"; unset = automatic */
+            if (ex && strcmp(ex, "rccl") && strcmp(ex, "host") && strcmp(ex, "auto")) {
+                log_fatal("TSP_GPU_EXCHANGE=\"%s\": expected rccl, host or auto", ex);
+                tspgpu_multi_destroy(g_multi); g_multi = NULL;
+                return NULL;
+            }
             if (ex && tspgpu_multi_set_option(g_multi, TSPGPU_MOPT_EXCHANGE, !strcmp(ex, "rccl") ? 2 : !strcmp(ex, "host") ? 1 : 0) != 0) {
                 log_fatal("TSP_GPU_EXCHANGE=%s: %s", ex, tspgpu_multi_last_error(g_multi));
                 tspgpu_multi_destroy(g_multi); g_multi = NULL;
@@ -203,12 +222,8 @@ ERROR_CODE tsp_compute_costs(void)
         }
         /* the RCCL communicator, if the exchange will use one: before the clock starts (main.c:177) */
         if ((rc = tspgpu_multi_prepare(m))) { log_error("tspgpu_multi_prepare: %s", tspgpu_multi_last_error(m)); return (ERROR_CODE)rc; }
-        if (tsp_matrix_free) return T_OK;
-        tsp_inst.costs = (double *)malloc(n * n * sizeof(double));
-        if (!tsp_inst.costs) return RESOURCE_EXHAUSTED;
-        rc = tspgpu_get_costs(g, tsp_inst.costs);
-        if (rc) { log_error("tspgpu_get_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
-        return T_OK;
+        if (tsp_matrix_free || tsp_lazy_costs) return T_OK;
+        return tsp_host_costs() ? T_OK : RESOURCE_EXHAUSTED;
     }
     rc = tspgpu_set_points(g, (const double *)tsp_inst.points, (int)n, tsp_edge_weight_kind);
     if (rc) { log_error("tspgpu_set_points: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
@@ -219,11 +234,32 @@ ERROR_CODE tsp_compute_costs(void)
         return T_OK;
     }
     tspgpu_set_option(g, TSPGPU_OPT_MATRIX_FREE, 0);
+    if (tsp_lazy_costs) {
+        rc = tspgpu_build_costs(g, NULL);
+        if (rc) { log_error("tspgpu_build_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
+        return T_OK;
+    }
     tsp_inst.costs = (double *)malloc(n * n * sizeof(double)); /* size_t: no int overflow past n = 46340 */
     if (!tsp_inst.costs) return RESOURCE_EXHAUSTED;
     rc = tspgpu_build_costs(g, tsp_inst.costs);
     if (rc) { log_error("tspgpu_build_costs: %s", tspgpu_last_error(g)); return (ERROR_CODE)rc; }
     return T_OK;
+}
+
+/* the host copy of the matrix (row-major n x n doubles, what the reference's tsp_inst.costs holds), downloaded from the
+ * device on first use when tsp_lazy_costs kept it away; NULL in matrix-free mode or when the allocation fails */
+double *tsp_host_costs(void)
+{
+    if (tsp_inst.costs || tsp_matrix_free || tsp_inst.nnodes <= 0) return tsp_inst.costs;
+    struct tspgpu_ctx *g = tsp_gpu();
+    if (!g) return NULL;
+    const size_t n = (size_t)tsp_inst.nnodes;
+    double *c = (double *)malloc(n * n * sizeof(double));
+    if (!c) { log_error("host copy of the cost matrix: out of memory (%zu bytes)", n * n * sizeof(double)); return NULL; }
+    const int rc = tspgpu_get_costs(g, c);
+    if (rc) { log_error("tspgpu_get_costs: %s", tspgpu_last_error(g)); free(c); return NULL; }
+    tsp_inst.costs = c;
+    return c;
 }
 
 /* one weight on the host with the arithmetic of tsp.c:629 (and TSPLIB's for ATT / CEIL_2D) */
@@ -237,9 +273,11 @@ static double host_weight(int i, int j)
     return ceil(sqrt(sq));
 }
 
+/* tsp.c:638-640.  Matrix-free instances (and a lazy copy that could not be allocated) compute the weight on demand. */
 double tsp_get_cost(int i, int j)
 {
-    return tsp_inst.costs ? tsp_inst.costs[(size_t)i * tsp_inst.nnodes + j] : host_weight(i, j);
+    const double *c = tsp_inst.costs ? tsp_inst.costs : (tsp_lazy_costs ? tsp_host_costs() : NULL);
+    return c ? c[(size_t)i * tsp_inst.nnodes + j] : host_weight(i, j);
 }
 
 /* tsp.c:687-728 */

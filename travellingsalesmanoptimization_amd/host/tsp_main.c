@@ -6,6 +6,9 @@
 
 int main(int argc, char *argv[])
 {
+    /* this executable runs the heuristic path only: nothing on the host reads the n x n matrix unless asked to */
+    const char *eager = getenv("TSP_EAGER_COSTS");
+    tsp_lazy_costs = !(eager && atoi(eager) != 0);
     ERROR_CODE e = tsp_parse_commandline(argc, argv);
     if (!err_ok(e)) {
         log_error("error in command line parsing, error code: %d", e);

@@ -165,6 +165,8 @@ extern int tsp_edge_weight_kind;
 /* true when no n x n matrix exists (n > 32 768 or TSP_MATRIX_FREE=1): tsp_inst.costs == NULL,
  * tsp_get_cost recomputes, the device runs its matrix-free kernels */
 extern bool tsp_matrix_free;
+extern bool tsp_lazy_costs;       /* tsp_inst.costs materialised on first use (tsp_core.c); the `tsp` executable sets it */
+double *tsp_host_costs(void);     /* tsp_inst.costs, downloaded from the device if it is not on the host yet */
 /* the device context behind tsp_inst.costs (created on first use; NULL if no MI355X) */
 struct tspgpu_ctx;
 struct tspgpu_ctx *tsp_gpu(void);
