@@ -711,7 +711,7 @@ def main():
                    "block": info["block"], "lds_bytes": info["lds_bytes"], "batch": args.batch,
                    "descent": ({"kernel": "k_lds2opt_w" if info_main.get("persist_window") else "k_lds2opt", "launches_per_descent": 1,
                                 "workgroups": info_main["persist_wgs"], "edges_per_workgroup": info_main["persist_edges"],
-                                "lds_bytes": info_main["persist_lds"], "block": 1024 if info_main.get("persist_window") else 512}
+                                "lds_bytes": info_main["persist_lds"], "block": 768 if info_main.get("persist_window") else 512}
                                if info_main.get("persist") else {"kernel": "one launch per sweep"}),
                    "parallelism": f"multistart-shard{world}"},
         "wall_clock_to_local_optimum_ms": 1e3 * tmax / args.steps,

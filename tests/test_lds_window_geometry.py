@@ -7,7 +7,7 @@ the cells k+1 .. k + n/2 + 1 inside its evaluated chunks.  A slip here would sho
 import numpy as np
 import pytest
 
-CUS, LW_EMAX, LW_BT, LW_FIX, LDS_MAX = 256, 24, 1024, 128, 160 * 1024
+CUS, LW_EMAX, LW_BT, LW_FIX, LDS_MAX = 256, 24, 768, 128, 160 * 1024
 POISON = 65535
 
 
@@ -107,26 +107,43 @@ class WG:
                     swp |= int(sw) << r
         jl = (lo - c_lo) % n
         inside = jl + M <= Ws
-        c1 = 0 if (inside or jl >= Ws) else Ws - jl
-        c2 = min(jl + M - n, Ws) if jl + M > n else 0
+        a1 = 0 if (inside or jl >= Ws) else Ws - jl
+        a2 = jl + M - n if jl + M > n else 0
+        rjl, rM = jl, (M if inside else 0)
+        fjl = fcnt = 0
         allrows = (2 << E) - 1
-        if c1 + c2 > LW_FIX:
+        if a1 and a2:
             need, swp = allrows, 0
-        if inside:
+        elif a1:
+            b = M - a1
+            fjl = jl
+            if a1 > b:
+                rjl, rM, fcnt = jl + b, a1 - b, b
+            else:
+                fcnt = a1
+        elif a2:
+            b = M - a2
+            if a2 > b:
+                rjl, rM, fjl, fcnt = 0, a2 - b, a2 - b, b
+            else:
+                fcnt = a2
+        if fcnt > LW_FIX:
+            need, swp = allrows, 0
+        if rM >= 2:
             for r in range(E + 1):
                 if not (need >> r) & 1:
-                    self.rows[r, jl:jl + M] = self.rows[r, jl:jl + M][::-1].copy()
+                    self.rows[r, rjl:rjl + rM] = self.rows[r, rjl:rjl + rM][::-1].copy()
         for r in range(E + 1):
             if (swp >> r) & 1:
                 self.rows[[r, mir[r]]] = self.rows[[mir[r], r]]
-        if c1 + c2 > 0 and need != allrows:
+        if fcnt > 0 and need != allrows:
             self.fixes += 1
             for r in range(E + 1):
                 if (need >> r) & 1:
                     continue
                 x = ord_new[(k0 + r) % n]
-                for cidx in range(c1 + c2):
-                    j = jl + cidx if cidx < c1 else cidx - c1
+                for cidx in range(fcnt):
+                    j = fjl + cidx
                     lq = ord_new[self.cell_of(j)]
                     self.rows[r, j] = POISON if lq == x else self.c[x, lq]
         for r in range(E + 1):
@@ -135,7 +152,7 @@ class WG:
                 self.reloads += 1
 
 
-@pytest.mark.parametrize("n,edges,seed", [(64, 0, 1), (97, 0, 2), (200, 3, 3), (333, 16, 4), (1000, 24, 5), (513, 0, 6)])
+@pytest.mark.parametrize("n,edges,seed", [(64, 0, 1), (97, 0, 2), (200, 3, 3), (333, 16, 4), (1000, 24, 5), (513, 0, 6), (3000, 0, 7)])
 def test_window_rows_follow_the_moves(n, edges, seed):
     g = geometry(n, edges)
     assert g is not None
@@ -148,8 +165,8 @@ def test_window_rows_follow_the_moves(n, edges, seed):
     wgs = [WG(c, ord_, n, E, Ws, w) for w in pick]
     for w in wgs:
         w.check(ord_)
-    lengths = [2, 3, 5, 8, 15, 16, 17, 40, 100, 129, n // 4, n // 2 - 1, n // 2]
-    for it in range(60):
+    lengths = [2, 3, 5, 8, 15, 16, 17, 40, 100, 129, n // 4, n // 2 - 1, n // 2, n // 2 - 20, 700, 1300]
+    for it in range(60 if n < 2000 else 32):
         M = max(2, min(n // 2, lengths[it % len(lengths)]))
         target = wgs[it % len(wgs)]
         # ranges placed around the interesting places of one workgroup: its own cells and both window ends
