@@ -221,7 +221,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=4096)
+    ap.add_argument("--n", "--size", dest="n", type=int, default=4096, help="nodes of the uniform-random instance (--size: unambiguous behind torch.distributed.run)")
     ap.add_argument("--seed", type=int, default=123)
     ap.add_argument("--elem", choices=["auto", "u16", "i32", "f64"], default=os.environ.get("TSPGPU_BENCH_ELEM", "auto"),
                     help="matrix storage; auto = the engine's default (narrowest exact copy)")

@@ -143,6 +143,23 @@ int tspgpu_tabu_move(tspgpu_ctx *ctx, int *path, double *cost, int *tabu_list, i
 int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k,
                        int *best_path, double *best_cost, double *trace);
 
+/* the loop of mh_VNS (src/algorithms/metaheuristic.c:279-318): k iterations of { ref_2opt (:290), incumbent (:298-302),
+ * r = rand() % 9 - 2 kicks (:308-318; vns_kick :344-409 = three tour positions under the reference's rejection rule, then
+ * tabu_make_move case 7, :490-500) }, resident on the device where the instance allows it (uint16 cells, n up to about
+ * 5400, an idle chip: the whole loop inside the LDS-resident kernel -- every workgroup applies the same kicks to its own
+ * copy of the tour, no exchange --, else one device local search per iteration with the kicks on the host).
+ * The random numbers are the CALLER's: rand_values[0 .. nrand) are rand() outputs drawn from the program's stream in
+ * order; *consumed says how many the call used, so that the caller's stream can continue exactly where the reference's
+ * would (host/tsp_algos.c keeps the rest queued).  In / out: path (the current tour; *cost is recomputed, refinment.c:6-9),
+ * *iterations (completed so far), *kick_pending (1: the local search of iteration *iterations is done, its kicks are not),
+ * best_path / *best_cost (the incumbent, strict <).  trace (may be NULL, else room for k - *iterations doubles): the cost
+ * of every local optimum reached by this call, trace[0] = iteration *iterations at entry (what the reference prints to
+ * results/VNSResults.dat).  Returns 0 when *iterations == k, 4 when the deadline passed,
+ * 8 when the numbers ran out in front of a kick phase -- state consistent, call again with more. */
+int tspgpu_vns_search(tspgpu_ctx *ctx, int *path, double *cost, int k, double time_left_s,
+                      const int *rand_values, long nrand, long *consumed, int *iterations, int *kick_pending,
+                      int *best_path, double *best_cost, double *trace);
+
 /* ---- multi-start entry points ------------------------------------------ */
 
 /* h_Greedy_iterative (src/algorithms/heuristics.c:34-72): NN from every listed

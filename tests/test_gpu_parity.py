@@ -1370,3 +1370,129 @@ def test_lds_resident_hands_over_mid_descent(T, O, instances, golden):
             assert (sweeps, gcost) == (gg["sweeps"], gg["final_cost"])
     finally:
         e.close()
+
+
+# ------------------------------------------------------------------ mh_VNS's loop on the device (tspgpu_vns_search)
+def _libc_draws(O, seed, count):
+    """the first `count` values of glibc's rand() stream after srand(seed) (what the reference's process would draw)"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    O.libc_srand(seed)
+    return np.array([libc.rand() for _ in range(count)], dtype=np.int32)
+
+
+def _oracle_vns(O, c, succ0, cost0, k, seed, rv):
+    """oracle VNS on the same stream; returns (best tour, best cost, final tour, numbers consumed)"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    O.libc_srand(seed)
+    s = succ0.copy()
+    best, bc = O.vns(c, s, cost0, k)
+    nxt = libc.rand()                                  # the value behind the last one the oracle consumed
+    used = int(np.nonzero(rv == nxt)[0][0])
+    assert rv[used] == nxt
+    return best, bc, s, used
+
+
+@pytest.mark.parametrize("mode", ["resident", "window", "host_kicks"])
+@pytest.mark.parametrize("name,k", [("kroA100", 200), ("n200_s3", 150), ("pr1002", 40), ("n1000_s123", 40)])
+def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
+    """mh_VNS (metaheuristic.c:279-318): k iterations of local search + kicks in ONE launch (LDS-resident kernels: whole rows
+    and half-window rows) and with the kicks on the host (the path every other instance takes): the incumbent, its cost,
+    the final (kicked) tour, the cost of every local optimum and the NUMBER of rand() values consumed equal the oracle's
+    on the same glibc stream"""
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST, 0 if mode == "host_kicks" else 2)
+    eng.set_option(T.OPT_PERSIST_WINDOW, 1 if mode == "window" else 0)
+    try:
+        seed0, cost0 = O.nn_tour(c, 7)
+        rv = _libc_draws(O, 5, 64 * k + 4096)
+        obest, obc, ofinal, oused = _oracle_vns(O, c, seed0, cost0, k, 5, rv)
+        path, best = seed0.copy(), seed0.copy()
+        r = eng.vns_search(path, k, rv, best, cost0, want_trace=True)
+        info = eng.info()
+        assert info["persist"] == (0 if mode == "host_kicks" else 1) and info["persist_window"] == (1 if mode == "window" else 0)
+        assert (r["rc"], r["iterations"], r["kick_pending"]) == (0, k, 0)
+        assert r["best_cost"] == obc and np.array_equal(best, obest)
+        assert np.array_equal(path, ofinal) and r["consumed"] == oused
+        assert O.valid_tour(best) and O.tour_cost(c, best) == obc
+        tr = r["trace"]
+        assert len(tr) == k and tr.min() == obc and not np.isnan(tr).any()
+    finally:
+        eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
+
+
+@pytest.mark.parametrize("mode", ["resident", "host_kicks"])
+def test_vns_search_refills_its_numbers(eng, T, O, instances, mode):
+    """the caller's random numbers run out in front of a kick phase: code 8, the tour of that local optimum, the iteration
+    and the pending flag come back; called again with the rest of the stream the walk continues to the oracle's result
+    -- and the numbers consumed add up to the oracle's"""
+    xy, c = setup(eng, T, O, instances, "n200_s3", 3, 0)
+    eng.set_option(T.OPT_PERSIST, 0 if mode == "host_kicks" else 2)
+    try:
+        k = 60
+        seed0, cost0 = O.nn_tour(c, 0)
+        rv = _libc_draws(O, 9, 64 * k + 4096)
+        obest, obc, ofinal, oused = _oracle_vns(O, c, seed0, cost0, k, 9, rv)
+        path, best = seed0.copy(), seed0.copy()
+        it = kp = 0
+        bc, used, calls = cost0, 0, 0
+        for give in (3, 5, 1, 40, 7, 100000):
+            r = eng.vns_search(path, k, rv[used:used + give], best, bc, iterations=it, kick_pending=kp)
+            calls += 1
+            it, kp, bc = r["iterations"], r["kick_pending"], r["best_cost"]
+            used += r["consumed"]
+            assert O.valid_tour(path)
+            if r["rc"] == 0:
+                break
+            assert r["rc"] == 8 and kp == 1 and it < k
+        assert calls >= 4 and (it, kp) == (k, 0)
+        assert bc == obc and np.array_equal(best, obest) and np.array_equal(path, ofinal) and used == oused
+    finally:
+        eng.set_option(T.OPT_PERSIST, 1)
+
+
+def test_vns_search_deadline(eng, T, O, instances):
+    """under a deadline the walk stops with code 4 after some iterations: a valid tour and incumbent, the incumbent's cost
+    its tour's cost, the numbers consumed so far reported"""
+    xy, c = setup(eng, T, O, instances, "n1000_s123", 3, 0)
+    seed0, cost0 = O.nn_tour(c, 0)
+    rv = _libc_draws(O, 3, 200000)
+    path, best = seed0.copy(), seed0.copy()
+    r = eng.vns_search(path, 100000, rv, best, cost0, time_left_s=0.05)
+    assert r["rc"] == 4 and 0 < r["iterations"] < 100000 and r["consumed"] > 0
+    assert O.valid_tour(path) and O.valid_tour(best) and O.tour_cost(c, best) == r["best_cost"] <= cost0
+
+
+def test_fused_two_chunks_both_labels_own(eng, T, O):
+    """regression (round 3): in the one-launch-per-sweep kernel with two chunks per thread (320 threads at n = 4461) a best
+    move whose labels are ~320 * 8 apart has BOTH labels among one thread's own b's; the winner's record must still name
+    the right run node.  The descent from the fixture tour (oracle/make_golden_vns_state.py) contains such a move
+    (376, 2938): every move, delta and the final cost against the oracle, for the default shape and its neighbours"""
+    import os
+    from conftest import GOLDEN_DIR
+    xy, _ = O.read_tsplib(data_path("fnl4461"))
+    c = O.cost_matrix(xy)
+    before = np.load(os.path.join(GOLDEN_DIR, "fnl4461_vns_it63.npy"))
+    start = O.tour_cost(c, before)
+    s2, cc, omoves = before.copy(), start, []
+    while True:
+        dd, cc, mv = O.two_opt_once(c, s2, cc)
+        if dd >= -1e-7:
+            break
+        omoves.append((mv[0], mv[1], dd))
+    assert (376, 2938, -1227.0) in omoves
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    try:
+        for persist, block in ((0, 0), (0, 384), (0, 576), (1, 0)):
+            eng.set_option(T.OPT_PERSIST, persist); eng.set_option(T.OPT_BLOCK, block)
+            s = before.copy()
+            eng.set_option(T.OPT_HISTORY, 4096)
+            cost, sw, rc = eng.two_opt(s)
+            a, b, d = eng.history(4096)
+            eng.set_option(T.OPT_HISTORY, 0)
+            got = [(int(a[j]), int(b[j]), float(d[j])) for j in range(len(omoves))]
+            assert got == omoves and sw == len(omoves) + 1 and cost == cc and np.array_equal(s, s2), (persist, block, eng.info())
+    finally:
+        eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_BLOCK, 0)

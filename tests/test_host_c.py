@@ -240,7 +240,7 @@ def test_bench_two_ranks_gloo_on_one_gpu():
     env = dict(os.environ, TSPGPU_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--n", "1024", "--seed", "1"],
+                          "--size", "1024", "--seed", "1"],
                          capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-3000:])
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -350,3 +350,185 @@ def test_vns_kick_matches_the_oracle_at_any_size(host, O, n):
     for _ in range(25):
         assert host.vns_kick(C.byref(sol)) == 0
     assert np.array_equal(got, want) and O.valid_tour(got)
+
+
+# ------------------------------------------------------------------ the reference's signatures, one by one (VERDICT r2 "weak" 1)
+class TabuSearch(C.Structure):   # tsp.h:105-113
+    _fields_ = [("tenure", C.c_int), ("max_tenure", C.c_int), ("min_tenure", C.c_int), ("increment", C.c_bool),
+                ("tabu_list", C.POINTER(C.c_int))]
+
+
+def test_host_make_move_and_reverse_path_against_the_compiled_reference(host):
+    """tabu_make_move cases 1-7 (metaheuristic.c:425-507: 1-3 single reversals, 4-6 the reference's two-step sequences with
+    their variable shuffles, 7 the VNS kick) and ref_reverse_path (refinment.c:95-114) are host code in the drop-in layer:
+    path AND prev after the call equal what the compiled reference leaves (tests/golden/golden_make_move.json,
+    oracle/make_golden_moves.py); with prev == NULL the layer builds its own and leaves the same path"""
+    import json
+    import numpy as np
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_make_move.json")))
+    ip = C.POINTER(C.c_int)
+    host.tabu_make_move.argtypes = [ip, C.POINTER(Solution)] + [C.c_int] * 7
+    host.ref_reverse_path.argtypes = [C.c_int] * 4 + [ip, ip]
+    host.ref_reverse_path.restype = None
+    host.tsp_init()
+    inst = Instance.in_dll(host, "tsp_inst")
+    seen = set()
+    for case in g["cases"]:
+        n = case["n"]
+        inst.nnodes = n
+        succ = np.array(case["succ"], dtype=np.int32)
+        path = succ.copy()
+        prev = np.empty(n, dtype=np.int32); prev[path] = np.arange(n, dtype=np.int32)
+        a = case["args"]
+        if case["case"] == 0:
+            host.ref_reverse_path(a[0], a[1], a[2], a[3], prev.ctypes.data_as(ip), path.ctypes.data_as(ip))
+        else:
+            sol = Solution(0.0, path.ctypes.data_as(ip), 0, None)
+            assert host.tabu_make_move(prev.ctypes.data_as(ip), C.byref(sol), case["case"], *a) == case["rc"]
+            p2 = succ.copy()
+            sol2 = Solution(0.0, p2.ctypes.data_as(ip), 0, None)
+            assert host.tabu_make_move(None, C.byref(sol2), case["case"], *a) == case["rc"]
+            assert p2.tolist() == case["path"], ("prev == NULL", case["case"], n)
+        assert path.tolist() == case["path"], (case["case"], n)
+        if case["case"] != 7:                       # (case 7 rewrites three successors and leaves prev alone)
+            assert prev.tolist() == case["prev"], (case["case"], n)
+        seen.add(case["case"])
+    assert seen == set(range(8))
+
+
+def _host_instance(host, name, env=None):
+    """tsp_parse_commandline + tsp_read_input (-> tsp_compute_costs on the device) through the library"""
+    for k, v in (env or {}).items():
+        os.environ[k] = v
+    try:
+        host.tsp_gpu_release()
+        rc, tenv, inst = parse(host, "-f", os.path.join(DATA, name + ".tsp"), "-q")
+        assert rc == 0
+        host.tsp_read_input()
+        host.utils_startclock(C.byref(inst, Instance.c.offset))
+    finally:
+        for k in (env or {}):
+            os.environ.pop(k, None)
+    return tenv, inst
+
+
+@pytest.mark.gpu
+def test_host_compute_costs_and_get_cost(host, O):
+    """tsp_compute_costs (tsp.c:608-636) fills tsp_inst.costs from the device build, tsp_get_cost (tsp.c:638-640) indexes it;
+    in matrix-free mode (no n x n array anywhere) tsp_get_cost recomputes the weight on the host: both against the oracle's
+    matrix, EUC_2D and -- TSP_ALLOW_EXT -- ATT"""
+    import numpy as np
+    host.tsp_get_cost.restype = C.c_double
+    host.tsp_get_cost.argtypes = [C.c_int, C.c_int]
+    for name, env in (("kroA100", {}), ("pr1002", {}), ("kroA100", {"TSP_MATRIX_FREE": "1"}), ("att48", {"TSP_ALLOW_EXT": "1"}),
+                      ("att48", {"TSP_ALLOW_EXT": "1", "TSP_MATRIX_FREE": "1"})):
+        tenv, inst = _host_instance(host, name, env)
+        xy, ewt = O.read_tsplib(os.path.join(DATA, name + ".tsp"))
+        c = O.cost_matrix(xy, {"EUC_2D": O.EUC_2D, "ATT": O.ATT}[ewt])
+        n = inst.nnodes
+        assert n == len(xy)
+        if "TSP_MATRIX_FREE" in env:
+            assert not inst.costs
+        else:
+            got = np.ctypeslib.as_array(C.cast(inst.costs, C.POINTER(C.c_double)), shape=(n, n))
+            assert np.array_equal(got, c)
+        rng = np.random.default_rng(3)
+        for i, j in [(0, 0), (0, 1), (n - 1, 0), (n - 1, n - 1)] + rng.integers(0, n, size=(200, 2)).tolist():
+            assert host.tsp_get_cost(int(i), int(j)) == c[i, j], (name, env, i, j)
+    host.tsp_free_instance()
+
+
+@pytest.mark.gpu
+def test_host_reference_signatures_on_the_device(host, O, golden):
+    """h_greedyutil(start, tsp_solution*, costs) (heuristics.c:216-288), ref_2opt_once(tsp_solution*, costs) looped as a
+    caller would (refinment.c:39-93: every delta, the golden cost trace and final tour), ref_2opt(.., update_incumbent),
+    tabu_best_move(path, cost, tabu_search*, iter) (metaheuristic.c:188-245: the reference goldens of 12 moves) -- through
+    libtsphost.so with the reference's own signatures and struct layouts"""
+    import numpy as np
+    ip = C.POINTER(C.c_int)
+    host.h_greedyutil.argtypes = [C.c_int, C.POINTER(Solution), C.c_void_p]
+    host.ref_2opt_once.argtypes = [C.POINTER(Solution), C.c_void_p]
+    host.ref_2opt_once.restype = C.c_double
+    host.ref_2opt.argtypes = [C.POINTER(Solution), C.c_void_p, C.c_bool]
+    host.tabu_best_move.argtypes = [ip, C.POINTER(C.c_double), C.POINTER(TabuSearch), C.c_int]
+    host.tsp_init_solution.argtypes = [C.c_int, C.POINTER(Solution)]
+    for name in ("kroA100", "pr1002"):
+        tenv, inst = _host_instance(host, name)
+        n = inst.nnodes
+        g = golden["instances"][name]["two_opt"]
+        sol = Solution()
+        assert host.tsp_init_solution(n, C.byref(sol)) == 0
+        assert host.h_greedyutil(0, C.byref(sol), inst.costs) == 0
+        path = np.ctypeslib.as_array(sol.path, shape=(n,))
+        assert sol.cost == g["nn_cost"] and "%016x" % O.fnv1a(path) == g["nn_fnv"]
+        assert host.h_greedyutil(n, C.byref(sol), inst.costs) == 14        # UNAVAILABLE: heuristics.c:224-227
+        assert host.h_greedyutil(0, C.byref(sol), inst.costs) == 0
+        nn = path.copy()
+        run, sweeps = sol.cost, 0
+        while True:
+            d = host.ref_2opt_once(C.byref(sol), inst.costs)
+            sweeps += 1
+            if d >= -1e-7:
+                break
+            run += d
+            assert sol.cost == run
+            if sweeps <= len(g["trace"]):
+                assert run == g["trace"][sweeps - 1]
+        assert (sweeps, sol.cost, "%016x" % O.fnv1a(path)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+        # ref_2opt with the incumbent update: the same local optimum from the NN tour, tsp_inst.best_solution takes it
+        path[:] = nn
+        inst.best_solution.path = C.cast(C.create_string_buffer(4 * n), ip)
+        inst.best_solution.cost = 1e300
+        assert host.ref_2opt(C.byref(sol), inst.costs, True) == 0
+        assert sol.cost == g["final_cost"] and inst.best_solution.cost == g["final_cost"]
+        assert "%016x" % O.fnv1a(np.ctypeslib.as_array(inst.best_solution.path, shape=(n,))) == g["final_fnv"]
+        inst.best_solution.path = None
+    for case in golden["tabu_move"]:
+        tenv, inst = _host_instance(host, case["instance"])
+        n = inst.nnodes
+        xy, _ = O.read_tsplib(os.path.join(DATA, case["instance"] + ".tsp"))
+        succ, cost = O.nn_tour(O.cost_matrix(xy), 0)
+        tl = np.full(n, -1, dtype=np.int32)
+        ts = TabuSearch(case["tenure"], 0, 0, True, tl.ctypes.data_as(ip))
+        cc = C.c_double(cost)
+        for it, want in enumerate(case["steps"]):
+            assert host.tabu_best_move(succ.ctypes.data_as(ip), C.byref(cc), C.byref(ts), it) == 0
+            assert (cc.value, "%016x" % O.fnv1a(succ), "%016x" % O.fnv1a(tl)) == (want["cost"], want["fnv"], want["tabu_fnv"])
+    host.tsp_free_instance()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy,tenure_of", [(0, lambda ts: 30), (1, lambda ts: -(-(ts[1] + ts[2]) // 2))])
+def test_host_tabu_search_other_policies(host, O, policy, tenure_of):
+    """mh_TabuSearch under the tenure policies no CLI flag selects (metaheuristic.c:126-143: POL_FIXED -> 30, POL_SIZE ->
+    ceil((max + min) / 2) -- integer division first, as in the reference): the loop steps through tabu_best_move on the
+    device; incumbent after k = 40 iterations against the oracle's moves with the same tenure"""
+    import numpy as np
+    tenv, inst = _host_instance(host, "kroA100")
+    n = inst.nnodes
+    xy, _ = O.read_tsplib(os.path.join(DATA, "kroA100.tsp"))
+    c = O.cost_matrix(xy)
+    tenv.policy = policy
+    tenv.k = 40
+    inst.best_solution.cost = 1e300
+    host.tsp_run_algorithm.restype = C.c_int
+    inst.alg = 3
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        assert host.tsp_run_algorithm() == 0
+    finally:
+        os.chdir(cwd)
+    # the oracle: h_greedy_2opt's winner, then 40 tabu moves with the policy's tenure, strict-< incumbent
+    best, bc, _, _ = O.multistart_nn_2opt(c)
+    succ, cost = best.copy(), bc
+    tl = np.full(n, -1, dtype=np.int32)
+    ts = (int(0.125 * n + 1), int(0.25 * n), int(0.125 * n))           # tabu_init: tenure, max, min (metaheuristic.c:65-84)
+    ten = tenure_of(ts)
+    for it in range(40):
+        cost, _ = O.tabu_move(c, succ, cost, tl, ten, it)
+        if cost < bc:
+            bc, best = cost, succ.copy()
+    assert inst.best_solution.cost == bc
+    assert np.array_equal(np.ctypeslib.as_array(inst.best_solution.path, shape=(n,)), best)
+    host.tsp_free_instance()

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""debug: the descent from the kicked tour of iteration 63 (fnl4461) under several kernel configurations vs the oracle"""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import oracle as O
+import travellingsalesmanoptimization_amd as T
+name, target = sys.argv[1], int(sys.argv[2])
+xy, _ = O.read_tsplib(os.path.join(ROOT, "tests", "golden", "data", name + ".tsp"))
+c = O.cost_matrix(xy)
+eng = T.Engine(0)
+eng.set_points(xy); eng.build_costs()
+seed, c0 = eng.nn_tour(0)
+c0, _, _ = eng.two_opt(seed)          # (LDS-resident)
+libc = ctypes.CDLL(None)
+O.libc_srand(1)
+succ = seed.copy()
+for it in range(target):
+    cost, sw, rc = eng.two_opt(succ)
+    r = libc.rand() % 9 - 2
+    for _ in range(r):
+        O.vns_kick(succ)
+before = succ.copy()
+start = O.tour_cost(c, before)
+# oracle's sequence
+s2 = before.copy(); cc = start; omoves = []
+while True:
+    dd, cc, mv = O.two_opt_once(c, s2, cc)
+    if dd >= -1e-7: break
+    omoves.append((mv[0], mv[1], dd))
+print("oracle:", len(omoves), "moves, final", cc)
+configs = [("fused default", {T.OPT_PERSIST: 0})] + [(f"fused block {bl}", {T.OPT_PERSIST: 0, T.OPT_BLOCK: bl}) for bl in (256, 320, 384, 448, 512, 576, 640, 1024)] + \
+          [(f"fused kernel 3 block {bl}", {T.OPT_PERSIST: 0, T.OPT_KERNEL: 3, T.OPT_BLOCK: bl}) for bl in (320, 576)] + \
+          [(f"split block {bl}", {T.OPT_PERSIST: 0, T.OPT_FUSED: 0, T.OPT_BLOCK: bl}) for bl in (320,)]
+for label, opts in configs:
+    for k, v in {T.OPT_PERSIST: 1, T.OPT_PIPE2: 1, T.OPT_FUSED: 1, T.OPT_BLOCK: 0, T.OPT_WGS_PER_TOUR: 0, T.OPT_KERNEL: 0}.items():
+        eng.set_option(k, v)
+    if T.OPT_ELEM in opts:
+        eng.set_option(T.OPT_ELEM, opts[T.OPT_ELEM]); eng.set_points(xy); eng.build_costs()
+    for k, v in opts.items():
+        if k != T.OPT_ELEM: eng.set_option(k, v)
+    s = before.copy()
+    eng.set_option(T.OPT_HISTORY, 4096)
+    cost, sw, rc = eng.two_opt(s)
+    a, b, d = eng.history(4096)
+    eng.set_option(T.OPT_HISTORY, 0)
+    i = eng.info()
+    wrong = [(j, omoves[j], (int(a[j]), int(b[j]), float(d[j]))) for j in range(min(len(omoves), len(a))) if (int(a[j]), int(b[j]), float(d[j])) != omoves[j]]
+    print(f"{label}: cost {cost} (true {O.tour_cost(c, s)}), sweeps {sw}, same tour {np.array_equal(s, s2)}, kernel {i['kernel']} block {i['block']} wgs {i['wgs_per_tour']} fused {i['fused']} pipe2 {i['pipe2']} persist {i['persist']}; wrong deltas: {wrong[:2]}")

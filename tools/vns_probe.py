@@ -1,43 +1,38 @@
 #!/usr/bin/env python3
-"""Short descents, the pattern of mh_VNS (metaheuristic.c:251-341: kick, then ref_2opt to the next local optimum, ~5 sweeps):
-time per tspgpu_two_opt call (path upload, descent, path download) with the LDS-resident kernel and with one launch per
-sweep.  The kick here is a random segment insertion on the host (a timing probe: it does not have to be the
-reference's vns_kick).  usage: python tools/vns_probe.py"""
-import os, sys, time
+"""mh_VNS's loop (metaheuristic.c:279-318) per iteration: the whole loop inside the LDS-resident kernel (tspgpu_vns_search,
+TSPGPU_OPT_PERSIST = 1) against one device local search per iteration with the kicks on the host (TSPGPU_OPT_PERSIST = 0:
+what every instance took in round 2).  The walk starts at the 2-opt local optimum of NN(0); the random numbers are
+glibc's rand() after srand(1).  usage: python tools/vns_probe.py [k]"""
+import ctypes, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from bench import read_tsplib, reference_points, draw_points
+draw_points([(4096, 123)])
+k = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+libc = ctypes.CDLL(None)
+libc.srand(1)
+rv = np.array([libc.rand() for _ in range(64 * k + 4096)], dtype=np.int32)
 import travellingsalesmanoptimization_amd as T
-from bench import read_tsplib, reference_points
 
-
-def kick(succ, rng):
-    """three random tour edges (A,sA) (B,sB) (C,sC) in tour order -> A->sB ... C->sA ... B->sC (an or-3opt segment move)"""
-    n = len(succ)
-    order = np.empty(n, dtype=np.int64)
-    v = 0
-    for p in range(n):
-        order[p] = v; v = succ[v]
-    i, j, k = sorted(rng.choice(n - 1, size=3, replace=False))
-    if j == i + 1 or k == j + 1:
-        return
-    A, sA, B, sB, C, sC = order[i], order[i + 1], order[j], order[j + 1], order[k], order[k + 1]
-    succ[A] = sB; succ[C] = sA; succ[B] = sC
-
-
-for name, xy in (("pr1002", read_tsplib(os.path.join(ROOT, "tests", "golden", "data", "pr1002.tsp"))[0]), ("n4096", reference_points(4096, 123))):
+for name, xy in (("pr1002", read_tsplib(os.path.join(ROOT, "tests", "golden", "data", "pr1002.tsp"))[0]), ("n4096", reference_points(4096, 123)),
+                 ("fnl4461", read_tsplib(os.path.join(ROOT, "tests", "golden", "data", "fnl4461.tsp"))[0])):
     eng = T.Engine(0)
     eng.set_points(xy); eng.build_costs()
-    for mode in (0, 1):
+    seed, c0 = eng.nn_tour(0)
+    c0, _, _ = eng.two_opt(seed)
+    res = {}
+    for mode in (1, 0):
         eng.set_option(T.OPT_PERSIST, mode)
-        succ, cost = eng.nn_tour(0)
-        cost, sw, rc = eng.two_opt(succ)
-        rng = np.random.default_rng(7)
-        tt = 0.0; tot = 0
-        for it in range(60):
-            kick(succ, rng)
+        kk = k if mode else max(50, k // 10)
+        ts = []
+        for rep in range(3 if mode else 2):
+            path, best = seed.copy(), seed.copy()
             t0 = time.perf_counter()
-            cost, sw, rc = eng.two_opt(succ)
-            tt += time.perf_counter() - t0; tot += sw
-        print(f"{name} persist={mode}: 60 kicks, {tot} sweeps, {tt*1e3:.2f} ms in two_opt = {tt/60*1e6:.1f} us per call, {tt/tot*1e6:.1f} us per sweep, final {cost:.0f}, used={eng.info()['persist']}", flush=True)
+            r = eng.vns_search(path, kk, rv, best, c0)
+            ts.append(time.perf_counter() - t0)
+        i = eng.info()
+        res[mode] = (r["best_cost"], r["consumed"])
+        print(f"{name} persist={mode} used={i['persist']} window={i['persist_window']}: {kk} iterations in {min(ts)*1e3:.2f} ms = {min(ts)/kk*1e6:.1f} us per iteration, "
+              f"best {r['best_cost']:.0f} (start {c0:.0f}), {r['consumed']} numbers consumed, rc={r['rc']}", flush=True)
     eng.close()

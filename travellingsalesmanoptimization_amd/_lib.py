@@ -48,6 +48,7 @@ SIGNATURES = {
     "tspgpu_two_opt": (C.c_int, [_ctx, _ip, _pd, C.c_double, _pl]),
     "tspgpu_tabu_move": (C.c_int, [_ctx, _ip, _pd, _ip, C.c_int, C.c_int]),
     "tspgpu_tabu_search": (C.c_int, [_ctx, _ip, _pd, C.c_int, _ip, _pd, C.c_void_p]),
+    "tspgpu_vns_search": (C.c_int, [_ctx, _ip, _pd, C.c_int, C.c_double, _ip, C.c_long, _pl, _pi, _pi, _ip, _pd, C.c_void_p]),
     "tspgpu_nn_all": (C.c_int, [_ctx, C.c_void_p, C.c_int, _ip, _pd, _pi]),
     "tspgpu_tour_sweep_part": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, _pd, _pi, _pi]),
     "tspgpu_tour_apply_move": (C.c_int, [_ctx, C.c_int, C.c_int, C.c_int, C.c_double]),

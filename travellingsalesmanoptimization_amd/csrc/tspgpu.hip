@@ -2287,19 +2287,25 @@ __global__ void __launch_bounds__(1024) k_sweep_fused(SweepArgs A)
         const int la = (int)(key >> 32), lb = (int)(key & 0xffffffffu);      // la < lb
         int own = -1, idx = 0, other = 0;
         if (winner) {
+            // which of the two labels is the thread's own b (the other one is the run node a).  With several chunks per
+            // thread BOTH can be own b's -- la in one chunk, lb in another (|lb - la| within V of a multiple of BT * V) --:
+            // then the orientation that was evaluated follows from the block rule of sweep_step_as (same block: b > a;
+            // else the pair belongs to the a whose block has b's block less than half way round ahead of it).
+            int idx_a = -1, idx_b = -1;
 #pragma unroll
-            for (int c = 0; c < NCH; c++) {       // both labels among the own b's: the pair came from a's own block, b > a
+            for (int c = 0; c < NCH; c++) {
                 const int b0c = (c * BT + tid) * V;
-                if ((unsigned)(lb - b0c) < (unsigned)V) { own = lb; idx = c * V + (lb - b0c); }
+                if ((unsigned)(lb - b0c) < (unsigned)V) idx_b = c * V + (lb - b0c);
+                if ((unsigned)(la - b0c) < (unsigned)V) idx_a = c * V + (la - b0c);
             }
-            if (own < 0) {
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const int b0c = (c * BT + tid) * V;
-                    if ((unsigned)(la - b0c) < (unsigned)V) { own = la; idx = c * V + (la - b0c); }
-                }
+            bool own_is_b = idx_b >= 0;
+            if (idx_a >= 0 && idx_b >= 0) {
+                const int NBk = (n + 64 * V - 1) / (64 * V), blka = la / (64 * V), blkb = lb / (64 * V);
+                int dblk = blkb - blka;                 // (la < lb: dblk >= 0)
+                own_is_b = dblk == 0 || 2 * dblk < NBk || (2 * dblk == NBk && blka < blkb);   // a = la evaluated b = lb
             }
-            other = own == lb ? la : lb;
+            own = own_is_b ? lb : la; idx = own_is_b ? idx_b : idx_a;
+            other = own_is_b ? la : lb;
             xch[0] = other;
         }
         // where in the run the pair's run node sits: one compare per thread instead of a serial walk by the winner
@@ -2886,7 +2892,8 @@ struct tspgpu_ctx {
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
-    int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk: the best tour by array cell [ld], its direction and flag [2]
+    int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk / VNS: the best tour by array cell [ld], its direction and flag [2]
+    int *d_vns_rand = nullptr; long vns_rand_cap = 0; int vns_launch_nrand = 0;   // VNS: the caller's rand() values of a launch
     int lp_skip = 0, lp_backoff = 16;   // the grid did not come up co-resident: the next lp_skip descents keep to the one-launch-per-sweep
                                         // path, then it is tried again (16, 32, ... 1024 descents apart while it keeps failing)
     bool lp_used = false;      // the last descent ran in k_lds2opt
@@ -3649,11 +3656,24 @@ static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, i
 // one-launch-per-sweep path.  Deadline: launches with a sweep budget of a third of the time left, measured per sweep;
 // every launch leaves a consistent tour (the sweep that ran is applied, refinment.c:17-26).
 struct PersistTabu { int k, tenure, t_min, t_max, up; double best; };
+// mh_VNS's loop in the LDS-resident kernels (tspgpu_lds_vns.inc): in/out state of tspgpu_vns_search across launches
+struct PersistVns {
+    int k;                  // iterations asked for in all
+    int it;                 // iterations completed
+    int phase;              // 1: the next launch resumes in the kick phase of iteration `it`
+    const int *h_rand;      // the caller's rand() values
+    long nrand, used;       // ... how many there are, how many have been consumed
+    double best;            // cost of the incumbent
+    double *h_trace;        // cost of every local optimum from iteration it_entry on, or nullptr
+    bool need_rand;         // out: stopped in front of a kick phase for want of numbers
+    int it_entry;           // `it` when the call was entered
+};
 
 // *time_left_io: the deadline budget; when the descent has to be handed to the one-launch-per-sweep path half way (the grid
 // lost its co-residency after the first launch: another context took CUs) it holds the time that is left and *ran stays
 // false -- the slot holds the consistent tour the last completed launch wrote back, the caller continues from there.
-static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *deadline_hit, bool *ran, const PersistTabu *tabu = nullptr)
+static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *deadline_hit, bool *ran, const PersistTabu *tabu = nullptr,
+                       PersistVns *vns = nullptr)
 {
     *ran = false;
     const double time_left_s = time_left_io ? *time_left_io : -1.0;
@@ -3670,7 +3690,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));      // exchange slots, then the control words
         HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
     }
-    if (tabu && ctx->lp_best_n < ctx->ld) {
+    if ((tabu || vns) && ctx->lp_best_n < ctx->ld) {
         if (ctx->d_lp_best) hipFree(ctx->d_lp_best);
         ctx->d_lp_best = nullptr; ctx->lp_best_n = 0;
         HIP_TRY(hipMalloc(&ctx->d_lp_best, ((size_t)ctx->ld + 16) * 4));
@@ -3691,6 +3711,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     double sweep_s = 8e-6;
     bool first = true, late = false;
     int retries = 0;
+    if (vns) vns->need_rand = false;
     // hand the rest of the descent to the per-sweep path (nothing of this launch was written: the slot is consistent)
     auto hand_over = [&]() {
         ctx->lp_handed = !first;
@@ -3707,7 +3728,29 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         }
         int *d_ctl = reinterpret_cast<int *>(ctx->d_lp_slots + (size_t)2 * W * 8);   // (one memset for both)
         HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64 + 64, ctx->stream));
-        if (tabu) HIP_TRY(hipMemsetAsync(ctx->d_lp_best + ctx->ld, 0, 8, ctx->stream));
+        if (tabu || vns) HIP_TRY(hipMemsetAsync(ctx->d_lp_best + ctx->ld, 0, 8, ctx->stream));
+        int vns_launch_k = 0;
+        if (vns) {
+            // this launch: at most 65536 iterations, the numbers they can be expected to need (a kick phase draws 1 + 3 per
+            // kick + the rejected ones, 8 on average; the kernel stops in front of a kick phase it cannot finish)
+            vns_launch_k = std::min(vns->k - vns->it, 65536);
+            const long want = std::min<long>(vns->nrand - vns->used, 32L * vns_launch_k + 1024);
+            if (want > ctx->vns_rand_cap) {
+                if (ctx->d_vns_rand) hipFree(ctx->d_vns_rand);
+                ctx->d_vns_rand = nullptr; ctx->vns_rand_cap = 0;
+                HIP_TRY(hipMalloc(&ctx->d_vns_rand, (size_t)(want + 64) * 4));
+                ctx->vns_rand_cap = want;
+            }
+            if (want > 0) HIP_TRY(hipMemcpyAsync(ctx->d_vns_rand, vns->h_rand + vns->used, (size_t)want * 4, hipMemcpyHostToDevice, ctx->stream));
+            if (vns->h_trace && vns_launch_k > ctx->trace_cap) {
+                if (ctx->d_trace) hipFree(ctx->d_trace);
+                ctx->d_trace = nullptr; ctx->trace_cap = 0;
+                HIP_TRY(hipMalloc(&ctx->d_trace, (size_t)vns_launch_k * 8));
+                ctx->trace_cap = vns_launch_k;
+                drop_graphs(ctx);
+            }
+            ctx->vns_launch_nrand = (int)want;
+        }
         PersistArgs A;
         memset(&A, 0, sizeof A);
         A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
@@ -3721,6 +3764,13 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             A.budget = -1;
             A.tabu_k = tabu->k; A.tenure0 = tabu->tenure; A.t_min = tabu->t_min; A.t_max = tabu->t_max; A.up0 = tabu->up;
             A.best0 = tabu->best; A.best_ord = ctx->d_lp_best; A.best_dir = ctx->d_lp_best + ctx->ld; A.trace = ctx->d_trace;
+            A.best_out = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost));
+        }
+        if (vns) {
+            A.vns_k = vns_launch_k; A.vns_it0 = vns->it; A.vns_phase = vns->phase;
+            A.vns_rand = ctx->d_vns_rand; A.vns_nrand = ctx->vns_launch_nrand; A.vns_state = d_ctl + 4;
+            A.best0 = vns->best; A.best_ord = ctx->d_lp_best; A.best_dir = ctx->d_lp_best + ctx->ld;
+            A.trace = vns->h_trace ? ctx->d_trace : nullptr;
             A.best_out = reinterpret_cast<double *>(reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost));
         }
         void *args[] = {&A};
@@ -3738,12 +3788,13 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             }
         }
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-        if (tabu) {
+        if (tabu || vns) {
             hipLaunchKernelGGL(k_lds_best_succ, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lp_best, ctx->d_lp_best + ctx->ld,
                                ctx->d_best_succ, ctx->n);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 32, hipMemcpyDeviceToHost, ctx->stream));
+        if (vns) HIP_TRY(hipMemcpyAsync(ctx->h_lp + 8, reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost), 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
         if (status == LP_ST_NO_RENDEZVOUS) {
@@ -3769,6 +3820,25 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             ctx->sweep_ms_total += ms; ctx->sweep_launches += sd;
         }
         if (sd > 0) sweep_s = (now_s() - t0) / sd;
+        if (vns) {
+            // what the launch completed: iterations, numbers, the incumbent's cost, the local optima's costs
+            const int it1 = ctx->h_lp[4];
+            if (vns->h_trace && it1 > vns->it) {
+                HIP_TRY(hipMemcpyAsync(vns->h_trace + (vns->it - vns->it_entry), ctx->d_trace, (size_t)(it1 - vns->it) * 8, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+            }
+            vns->it = it1; vns->used += ctx->h_lp[5]; vns->phase = ctx->h_lp[6];
+            memcpy(&vns->best, ctx->h_lp + 8, 8);
+            if (status == LP_ST_NEED_RAND) {
+                // out of numbers -- of this launch's window, or of all the caller gave
+                if (vns->used + ctx->vns_launch_nrand - ctx->h_lp[5] >= vns->nrand) { vns->need_rand = true; break; }
+                continue;
+            }
+            if (status == LP_ST_VNS_DONE) {
+                if (vns->it >= vns->k) break;
+                continue;                              // (a launch completes at most 65536 iterations)
+            }
+        }
         if (status == LP_ST_OPTIMUM || status == LP_ST_CAPPED) break;
     }
     if (late && deadline_hit) *deadline_hit = true;
@@ -4192,6 +4262,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_lp_slots) hipFree(ctx->d_lp_slots);
     if (ctx->h_ord) hipHostFree(ctx->h_ord);
     if (ctx->d_lp_best) hipFree(ctx->d_lp_best);
+    if (ctx->d_vns_rand) hipFree(ctx->d_vns_rand);
     if (ctx->ev_ord) hipEventDestroy(ctx->ev_ord);
     if (ctx->h_lp) hipHostFree(ctx->h_lp);
     if (ctx->d_trace) hipFree(ctx->d_trace);
@@ -4639,6 +4710,96 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
     if ((rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
     *best_cost = ts.best_cost;
     return E_OK;
+}
+
+// host side of vns_kick (metaheuristic.c:344-409, :490-500) for the non-resident path of tspgpu_vns_search: the same
+// draws, the same rejection rule, the same unwrapped probes as tspgpu_lds_vns.inc (and as oracle/cpu_ref.c models them)
+static bool vns_kick_host(std::vector<int> &succ, std::vector<int> &tour, const int *rv, long nrand, long &cur)
+{
+    const int n = (int)succ.size();
+    for (int p = 0, v = 0; p < n; p++, v = succ[v]) tour[p] = v;
+    auto at = [&](int p) { return p < 0 ? 0 : p >= n ? ((n & 3) == 2 ? -2 : 0) : tour[p]; };
+    int pick[3];
+    for (int i = 0; i < 3; i++) {
+        int r = -1;
+        while (r < 0) {
+            if (cur >= nrand) return false;
+            r = (int)((unsigned)rv[cur++] % (unsigned)n);
+            for (int j = 0; j < i; j++)
+                if (r == pick[j] || r == at(pick[j] - 1) || r == at(pick[j] + 1)) { r = -1; break; }
+        }
+        pick[i] = r;
+        for (int j = i; j > 0 && pick[j] < pick[j - 1]; j--) std::swap(pick[j], pick[j - 1]);
+    }
+    const int a = tour[pick[0]], sa = tour[(pick[0] + 1) % n], b = tour[pick[1]], sb = tour[(pick[1] + 1) % n],
+              c = tour[pick[2]], sc = tour[(pick[2] + 1) % n];
+    succ[a] = sb; succ[c] = sa; succ[b] = sc;
+    return true;
+}
+
+int tspgpu_vns_search(tspgpu_ctx *ctx, int *path, double *cost, int k, double time_left_s, const int *rand_values, long nrand,
+                      long *consumed, int *iterations, int *kick_pending, int *best_path, double *best_cost, double *trace)
+{
+    if (!ctx || !path || !cost || !best_path || !best_cost || !iterations || !kick_pending || !consumed || k < 0 || nrand < 0 ||
+        (nrand > 0 && !rand_values) || *iterations < 0 || *iterations > k)
+        return fail(ctx, E_INVALID, "bad argument");
+    hipSetDevice(ctx->device);
+    int rc = need_costs(ctx);
+    if (rc) return rc;
+    const int n = ctx->n;
+    *consumed = 0;
+    if (*iterations >= k) return E_OK;
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    if ((rc = load_path(ctx, 0, path, -1))) return rc;              // (recomputes the cost: refinment.c:6-9)
+    bool resident_done = false;
+    ctx->lp_used = false;
+    PersistVns pv = {k, *iterations, *kick_pending ? 1 : 0, rand_values, nrand, 0, *best_cost, trace, false, *iterations};
+    bool late = false;
+    if (ctx->symmetric && (ctx->opt_persist == 2 || (ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1))) {
+        HIP_TRY(hipMemcpyAsync(ctx->d_best_succ, best_path, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+        double left = t_end >= 0 ? std::max(0.0, t_end - now_s()) : -1.0;
+        bool ran = false;
+        ctx->lp_handed = false;
+        if ((rc = run_persist(ctx, 0, &left, &late, &ran, nullptr, &pv))) return rc;
+        if (ctx->lp_handed) return fail(ctx, E_INTERNAL, "LDS-resident VNS: the grid lost its co-residency half way");
+        resident_done = ran;
+        if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident VNS loop does not apply (uint16 cells, n in [64, ~5400], one idle chip)");
+        if (ran) HIP_TRY(hipMemcpyAsync(best_path, ctx->d_best_succ, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (!resident_done) {
+        // one local search per iteration on the device (whatever kernels the instance takes), kicks on the host
+        std::vector<int> succ(path, path + n), tour(n), before(n);
+        long cur = 0;
+        while (pv.it < k) {
+            if (t_end >= 0 && now_s() >= t_end) { late = true; break; }
+            if (!pv.phase) {
+                if ((rc = load_path(ctx, 0, succ.data(), -1))) return rc;
+                bool l2 = false;
+                if ((rc = run_sweeps(ctx, 0, 1, false, -1, t_end >= 0 ? std::max(0.0, t_end - now_s()) : -1.0, &l2))) return rc;
+                double c = 0;
+                if ((rc = store_path(ctx, 0, succ.data(), &c, nullptr))) return rc;
+                if (c < pv.best) { pv.best = c; memcpy(best_path, succ.data(), (size_t)n * 4); }
+                if (trace) trace[pv.it - pv.it_entry] = c;
+                *cost = c;
+            }
+            const long cur0 = cur;
+            before = succ;
+            bool dry = cur >= nrand;
+            if (!dry) {
+                const int kicks = rand_values[cur++] % 9 - 2;
+                for (int j = 0; j < kicks && !dry; j++) dry = !vns_kick_host(succ, tour, rand_values, nrand, cur);
+            }
+            if (dry) { succ = before; cur = cur0; pv.phase = 1; pv.need_rand = true; break; }
+            pv.phase = 0; pv.it++;
+        }
+        pv.used = cur;
+        memcpy(path, succ.data(), (size_t)n * 4);
+    } else {
+        if ((rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
+    }
+    *iterations = pv.it; *kick_pending = pv.phase; *consumed = pv.used; *best_cost = pv.best;
+    if (pv.need_rand) return fail(ctx, E_EXHAUSTED, "the random numbers ran out in front of the kicks of iteration %d: call again with more", pv.it);
+    return late ? E_DEADLINE : E_OK;
 }
 
 int tspgpu_nn_all_timed(tspgpu_ctx *ctx, const int *starts, int nstarts, double time_left_s, int *best_path, double *best_cost,

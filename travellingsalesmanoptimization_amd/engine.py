@@ -114,6 +114,19 @@ class Engine:
                                            trace.ctypes.data if want_trace else None))
         return best, bc.value, c.value, (trace[:k] if want_trace else None)
 
+    def vns_search(self, path, k, rand_values, best_path, best_cost, iterations=0, kick_pending=0, time_left_s=-1.0, want_trace=False):
+        """mh_VNS's loop (metaheuristic.c:279-318); path and best_path in place ->
+        dict(rc, cost, best_cost, iterations, kick_pending, consumed, trace)."""
+        rv = np.ascontiguousarray(rand_values, dtype=np.int32)
+        c, bc = C.c_double(), C.c_double(best_cost)
+        used, it, kp = C.c_long(), C.c_int(iterations), C.c_int(kick_pending)
+        trace = np.full(max(k - iterations, 1), np.nan, dtype=np.float64) if want_trace else None
+        rc = self._ck(self.L.tspgpu_vns_search(self.ctx, path, C.byref(c), int(k), float(time_left_s), rv, len(rv), C.byref(used),
+                                               C.byref(it), C.byref(kp), best_path, C.byref(bc), trace.ctypes.data if want_trace else None),
+                      ok=(T_OK, DEADLINE_EXCEEDED, 8))
+        return {"rc": rc, "cost": c.value, "best_cost": bc.value, "iterations": it.value, "kick_pending": kp.value,
+                "consumed": used.value, "trace": trace}
+
     # ---- multi-start
     @staticmethod
     def _starts(starts, n):

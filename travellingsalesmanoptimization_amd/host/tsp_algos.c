@@ -492,8 +492,11 @@ ERROR_CODE tabu_make_move(int *prev, tsp_solution *solution, int bestCase, int i
     return T_OK;
 }
 
-/* metaheuristic.c:251-341: 2-opt on the device, kicks on the host (glibc rand(), never
- * re-implemented on the device) */
+/* metaheuristic.c:251-341.  The loop -- local search, incumbent, r = rand() % 9 - 2 kicks -- runs on the device
+ * (tspgpu_vns_search: inside the LDS-resident kernel where the instance allows it).  The random numbers stay the
+ * program's: they are drawn here from the glibc stream (tsp_rand_peek), handed over in order, and what the device did
+ * not use stays queued for the next draw, so the stream is consumed exactly as by the reference binary.  TSP_VNS_HOST=1
+ * keeps the loop on the host (one ref_2opt call per iteration, vns_kick above). */
 ERROR_CODE mh_VNS(void)
 {
     log_info("running Variable Neighborhood Search");
@@ -510,18 +513,47 @@ ERROR_CODE mh_VNS(void)
 
     FILE *f = fopen("results/VNSResults.dat", "w+");
     e = T_OK;
-    for (int it = 0; it < tsp_env.k; it++) {
-        if (past_deadline()) { e = DEADLINE_EXCEEDED; break; }
-        e = ref_2opt(&s, tsp_inst.costs, true);
-        if (!err_ok(e)) { log_fatal("code %d : Error in local search", e); tsp_handlefatal(); }
-        if (s.cost < best.cost) {
-            log_info("found new best: %f ", s.cost);
-            best.cost = s.cost;
-            memcpy(best.path, s.path, (size_t)n * sizeof(int));
+    const char *on_host = getenv("TSP_VNS_HOST");
+    if (on_host && atoi(on_host)) {
+        for (int it = 0; it < tsp_env.k; it++) {
+            if (past_deadline()) { e = DEADLINE_EXCEEDED; break; }
+            e = ref_2opt(&s, tsp_inst.costs, true);
+            if (!err_ok(e)) { log_fatal("code %d : Error in local search", e); tsp_handlefatal(); }
+            if (s.cost < best.cost) {
+                log_info("found new best: %f ", s.cost);
+                best.cost = s.cost;
+                memcpy(best.path, s.path, (size_t)n * sizeof(int));
+            }
+            if (f) fprintf(f, "%d,%f\n", it, s.cost);
+            const int kicks = tsp_rand() % (UPPER - LOWER + 1) - LOWER;
+            for (int j = 0; j < kicks; j++) vns_kick(&s);
         }
-        if (f) fprintf(f, "%d,%f\n", it, s.cost);
-        const int kicks = tsp_rand() % (UPPER - LOWER + 1) - LOWER;
-        for (int j = 0; j < kicks; j++) vns_kick(&s);
+    } else {
+        tspgpu_ctx *g = tsp_gpu();
+        if (!g) return UNAVAILABLE;
+        enum { CHUNK = 16384 };                     /* iterations per call: bounds the trace buffer and the numbers drawn ahead */
+        double *trace = f ? (double *)malloc(CHUNK * sizeof(double)) : NULL;
+        int it = 0, pending = 0;
+        while (it < tsp_env.k) {
+            if (past_deadline()) { e = DEADLINE_EXCEEDED; break; }
+            const int upto = tsp_env.k - it > CHUNK ? it + CHUNK : tsp_env.k;
+            const long want = 32L * (upto - it) + 1024;
+            const int *rv = tsp_rand_peek(want);
+            if (!rv) { log_fatal("out of memory for %ld random numbers", want); tsp_handlefatal(); }
+            long used = 0;
+            const int it0 = it;
+            const double best0 = best.cost;
+            const int rc = tspgpu_vns_search(g, s.path, &s.cost, upto, time_left(), rv, want, &used, &it, &pending, best.path, &best.cost, trace);
+            tsp_rand_consume(used);
+            if (rc != 0 && rc != DEADLINE_EXCEEDED && rc != RESOURCE_EXHAUSTED) {
+                log_fatal("code %d : Error in local search: %s", rc, tspgpu_last_error(g));
+                tsp_handlefatal();
+            }
+            if (best.cost < best0) log_info("found new best: %f ", best.cost);
+            if (f && trace) for (int i = it0; i < it; i++) fprintf(f, "%d,%f\n", i, trace[i - it0]);
+            if (rc == DEADLINE_EXCEEDED) { e = DEADLINE_EXCEEDED; break; }
+        }
+        free(trace);
     }
     if (f) fclose(f);
     ERROR_CODE u = tsp_update_best_solution(&best);

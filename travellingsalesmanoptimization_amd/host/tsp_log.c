@@ -126,7 +126,13 @@ static char *rng_enter(void)
     return setstate(g_rng_table);
 }
 
-int tsp_rand(void)
+/* Values drawn ahead for the device (mh_VNS's kicks run inside the kernel on numbers handed over in a buffer,
+ * tspgpu_vns_search) and not consumed there stay queued: tsp_rand() serves them first, so the program's stream continues
+ * exactly where the reference's would. */
+static int *g_rng_q = NULL;
+static long g_rng_q_head = 0, g_rng_q_len = 0, g_rng_q_cap = 0;
+
+static int rng_draw(void)
 {
     char *prev = rng_enter();
     const int r = rand();
@@ -134,11 +140,41 @@ int tsp_rand(void)
     return r;
 }
 
+int tsp_rand(void)
+{
+    if (g_rng_q_head < g_rng_q_len) return g_rng_q[g_rng_q_head++];
+    return rng_draw();
+}
+
+/* the next `count` values of the stream, without consuming them (NULL if the queue cannot grow) */
+const int *tsp_rand_peek(long count)
+{
+    if (g_rng_q_head > 0) {
+        memmove(g_rng_q, g_rng_q + g_rng_q_head, (size_t)(g_rng_q_len - g_rng_q_head) * sizeof(int));
+        g_rng_q_len -= g_rng_q_head; g_rng_q_head = 0;
+    }
+    if (count > g_rng_q_cap) {
+        int *q = (int *)realloc(g_rng_q, (size_t)count * sizeof(int));
+        if (!q) return NULL;
+        g_rng_q = q; g_rng_q_cap = count;
+    }
+    while (g_rng_q_len < count) g_rng_q[g_rng_q_len++] = rng_draw();
+    return g_rng_q;
+}
+
+/* the first `count` peeked values have been used */
+void tsp_rand_consume(long count)
+{
+    g_rng_q_head += count;
+    if (g_rng_q_head > g_rng_q_len) g_rng_q_head = g_rng_q_len;
+}
+
 void tsp_srand(unsigned seed)
 {
     char *prev = rng_enter();
     srand(seed);
     setstate(prev);
+    g_rng_q_head = g_rng_q_len = 0;      /* values drawn ahead belonged to the old seed */
 }
 
 ERROR_CODE tsp_init_solution(int nnodes, tsp_solution *s)

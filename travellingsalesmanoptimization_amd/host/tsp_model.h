@@ -54,6 +54,8 @@ void err_setinfo(int alg, int nnodes, bool random, char *inputfile, double timel
 #define TSP_RAND() (((double)tsp_rand() / RAND_MAX) * (MAX_COORDINATE - MIN_COORDINATE) + MIN_COORDINATE)
 int tsp_rand(void);            /* glibc rand() on the program's private stream (see tsp_log.c) */
 void tsp_srand(unsigned seed);
+const int *tsp_rand_peek(long count);   /* the next `count` values of that stream, not consumed (for tspgpu_vns_search) */
+void tsp_rand_consume(long count);      /* ... of which the first `count` have now been used */
 #define NOT_CONNECTED -1.0f
 #define utils_safe_free(pointer) utils_safe_memory_free((void **)&(pointer))
 
