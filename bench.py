@@ -77,6 +77,17 @@ def reference_points(n, seed):
     return xy.copy()
 
 
+_VNS_RAND = None
+
+
+def libc_rand_values(seed, count):
+    """the first `count` values of glibc's rand() after srand(seed) (the stream a reference process would draw from)"""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.srand(ctypes.c_uint(seed))
+    return np.array([libc.rand() for _ in range(count)], dtype=np.int32)
+
+
 def draw_points(sets):
     """every uniform-random instance of the run, drawn before HIP is initialised; later requests must hit the cache"""
     for n, seed in sets:
@@ -246,6 +257,8 @@ def main():
         args.batch_starts = 0
 
     draw_points([(args.n, args.seed), (1024, 1), (16384, 123), (1024, 123), (3584, 123), (4096, 123)])
+    global _VNS_RAND
+    _VNS_RAND = libc_rand_values(1, 64 * 1000 + 4096)          # the VNS leg's numbers: also before HIP is initialised
     import torch
     import torch.distributed as dist
     import travellingsalesmanoptimization_amd as T
@@ -664,6 +677,44 @@ def main():
             return out
         tabu = guarded(tabu_leg)
 
+    # ---- mh_VNS's loop (metaheuristic.c:279-318): local search + kicks, resident in the LDS kernels and with the kicks on the host
+    vns = None
+    if aux and not args.no_sizes:
+        def vns_leg():
+            out = {"what": "iterations of { ref_2opt, incumbent, rand() % 9 - 2 kicks } from the 2-opt local optimum of NN(0); the random "
+                           "numbers are glibc rand() values after srand(1), drawn on the host before the first GPU call",
+                   "note": "an iteration is ~10 sweeps (2.3 kicks on average, each repaired by several long reversals), not the ~5 of a "
+                           "single-kick descent"}
+            for name, pts in (("pr1002", read_tsplib(os.path.join(DATA, "pr1002.tsp"))[0]), ("n4096_s123", reference_points(4096, 123)),
+                              ("fnl4461", read_tsplib(os.path.join(DATA, "fnl4461.tsp"))[0])):
+                e6 = T.Engine(local)
+                try:
+                    e6.set_points(pts); e6.build_costs()
+                    seed0, c0 = e6.nn_tour(0)
+                    c0, _, _ = e6.two_opt(seed0)
+                    row = {}
+                    for mode, label, kk in ((1, "resident", 1000), (0, "host_kicks", 100)):
+                        e6.set_option(T.OPT_PERSIST, mode)
+                        ts = []
+                        for _ in range(2):
+                            p6, b6 = seed0.copy(), seed0.copy()
+                            t1 = time.perf_counter()
+                            r6 = e6.vns_search(p6, kk, _VNS_RAND, b6, c0)
+                            ts.append(time.perf_counter() - t1)
+                        i6 = e6.info()
+                        row[label] = {"iterations": kk, "us_per_iteration": 1e6 * min(ts) / kk, "best_cost": r6["best_cost"],
+                                      "rand_values_consumed": r6["consumed"], "rc": r6["rc"],
+                                      "kernel": ("k_lds2opt_w" if i6["persist_window"] else "k_lds2opt") + " (whole loop in one launch)" if i6["persist"]
+                                                else "one device local search per iteration, kicks on the host"}
+                        if i6["persist"]:
+                            row[label].update({"sweeps": i6["persist_sweeps"], "sweeps_per_iteration": i6["persist_sweeps"] / kk,
+                                               "us_per_sweep_all_in": 1e6 * min(ts) / max(i6["persist_sweeps"], 1)})
+                    out[name] = row
+                finally:
+                    e6.close()
+            return out
+        vns = guarded(vns_leg)
+
     # ---- the drop-in binary: C host layer, multi-start sharded in C over the N devices of this run, RCCL exchange.
     # A child process (its own HIP context); at N > 1 the other ranks have left and released their devices.
     host_c = None
@@ -719,7 +770,7 @@ def main():
         "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
         "roofline": roof, "roofline_one_launch_per_sweep": roof_fused, "roofline_build": broof, "cpu_baseline": base,
         "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
-        "tabu_walk": tabu, "config2_fnl4461": cfg2,
+        "tabu_walk": tabu, "vns_walk": vns, "config2_fnl4461": cfg2,
     }
     if base and "value" in base:
         out["gpu_over_cpu"] = out["value"] / base["value"]

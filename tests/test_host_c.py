@@ -216,7 +216,7 @@ def test_bench_line_contract():
     assert r["traffic"] is None and "traffic_from_committed_profile" in r   # PMC bytes are not measured by the run itself
     b = d["roofline_build"]
     assert b["bound"] == "hbm" and b["kernel"].startswith("k_build_costs") and abs(b["frac"] - b["achieved"] / 8000.0) < 1e-9
-    for k in ("sizes", "otf", "cpu_multistart_baseline", "host_c_path", "other_matrix_storage", "multistart_batch", "tabu_walk", "config2_fnl4461"):
+    for k in ("sizes", "otf", "cpu_multistart_baseline", "host_c_path", "other_matrix_storage", "multistart_batch", "tabu_walk", "vns_walk", "config2_fnl4461"):
         assert k in d
     assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["kind"] in ("reference", "port")
     assert abs(d["value"] - 609 * 8382464 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6

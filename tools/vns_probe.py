@@ -33,6 +33,8 @@ for name, xy in (("pr1002", read_tsplib(os.path.join(ROOT, "tests", "golden", "d
             ts.append(time.perf_counter() - t0)
         i = eng.info()
         res[mode] = (r["best_cost"], r["consumed"])
+        sw = i["persist_sweeps"] if mode else 0
+        extra = f", {sw} sweeps = {sw/kk:.1f} per iteration, {min(ts)/max(sw,1)*1e6:.2f} us per sweep all in" if sw else ""
         print(f"{name} persist={mode} used={i['persist']} window={i['persist_window']}: {kk} iterations in {min(ts)*1e3:.2f} ms = {min(ts)/kk*1e6:.1f} us per iteration, "
-              f"best {r['best_cost']:.0f} (start {c0:.0f}), {r['consumed']} numbers consumed, rc={r['rc']}", flush=True)
+              f"best {r['best_cost']:.0f} (start {c0:.0f}), {r['consumed']} numbers consumed ({r['consumed']/kk:.1f} per iteration), rc={r['rc']}{extra}", flush=True)
     eng.close()

@@ -2888,6 +2888,7 @@ struct tspgpu_ctx {
     int opt_persist_window = 0; // 0 auto (half-window rows where whole rows do not fit the chip's LDS), 1 always, 2 never
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
     bool lp_handed = false;    // run_persist began a descent and handed the rest to the per-sweep path
+    long lp_sweeps = 0;        // sweeps run by the launches of the last LDS-resident descent / walk
     bool lpw_attr[2] = {false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
@@ -3712,6 +3713,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     bool first = true, late = false;
     int retries = 0;
     if (vns) vns->need_rand = false;
+    ctx->lp_sweeps = 0;
     // hand the rest of the descent to the per-sweep path (nothing of this launch was written: the slot is consistent)
     auto hand_over = [&]() {
         ctx->lp_handed = !first;
@@ -3814,6 +3816,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             return fail(ctx, E_INTERNAL, "LDS-resident descent: no status written (after %d sweeps)", sd);
         first = false;
         ctx->lp_backoff = 16;
+        ctx->lp_sweeps += sd;
         if (ctx->opt_timing && sd > 0) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
@@ -4353,6 +4356,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     }
     case 20: return ctx->lp_used && ctx->lp_window ? 1 : 0;
     case 21: return ctx->lp_handed ? 1 : 0;
+    case 22: return ctx->lp_sweeps;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
