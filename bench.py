@@ -370,7 +370,7 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "kernel_ms_mean": ms,
-                "kernel": "k_build_costs<double>" if info["elem"] == T.ELEM_F64 else f"k_build_costs_int<{CTYPE[info['elem']]}, kind>",
+                "kernel": "k_build_costs<double>" if info["elem"] == T.ELEM_F64 else (f"k_build_costs_tri<{CTYPE[info['elem']]}, kind> (upper triangle computed once, every 64 x 64 tile stored twice)" if info["n"] >= 128 else f"k_build_costs_int<{CTYPE[info['elem']]}, kind>"),
                 "algorithmic_bytes_per_launch": nbytes, "bytes_per_cell": BYTES[info["elem"]],
                 "f64_cells_equivalent_GBs": 8 * info["n"] * info["ld"] / (ms * 1e-3) / 1e9}
 
@@ -652,7 +652,7 @@ def main():
     if aux and not args.no_sizes:
         def tabu_leg():
             k, out = 2000, {}
-            for tn in (1024, 3584):
+            for tn in (1024, 3584, 4096):
                 e4 = T.Engine(local)
                 try:
                     e4.set_option(T.OPT_ELEM, T.ELEM_U16)
@@ -668,7 +668,9 @@ def main():
                             t1 = time.perf_counter()
                             _, bc, fc, _ = e4.tabu_search(s0, c0, k)
                             ts.append(time.perf_counter() - t1)
-                        row[name] = {"us_per_iteration": 1e6 * min(ts) / k, "kernel": "k_lds2opt<.,true>" if e4.info()["persist"] else "k_sweep_*<TABU> + k_apply",
+                        i4 = e4.info()
+                        row[name] = {"us_per_iteration": 1e6 * min(ts) / k,
+                                     "kernel": ("k_lds2opt_w<.,true> (half-window rows)" if i4["persist_window"] else "k_lds2opt<.,true>") if i4["persist"] else "k_sweep_*<TABU> + k_apply",
                                      "best_cost": bc, "final_cost": fc}
                     row["same_walk"] = row["lds_resident"]["final_cost"] == row["sweep_apply_kernels"]["final_cost"]
                     out[str(tn)] = row

@@ -1496,3 +1496,102 @@ def test_fused_two_chunks_both_labels_own(eng, T, O):
             assert got == omoves and sw == len(omoves) + 1 and cost == cc and np.array_equal(s, s2), (persist, block, eng.info())
     finally:
         eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_BLOCK, 0)
+
+
+# ------------------------------------------------------------------ the tabu walk in the half-window kernel (k_lds2opt_w<., true>)
+@pytest.mark.parametrize("edges", [0, 6, 24])
+@pytest.mark.parametrize("name,k", [("kroA100", 400), ("n200_s3", 400), ("pr1002", 200), ("n1000_s123", 200), ("n1024_s1", 150)])
+def test_lds_window_tabu_walk(eng, T, O, instances, name, k, edges, window):
+    """mh_TabuSearch's k iterations in ONE launch of the half-window kernel (ages by array cell in LDS, neighbour cells
+    poisoned and patched per move -- where the window holds them --, crossing ranges re-read with the poison in place):
+    the cost after EVERY iteration, the final tour, the best tour and its cost equal the oracle's; packed 16-bit form
+    (costs <= 8190: kroA100, n200) and the 32-bit form"""
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    eng.set_option(T.OPT_PERSIST_EDGES, edges)
+    if eng.info()["persist_window_cells"] == 0:
+        pytest.skip("the window of this many edges does not fit n")
+    seed, cost = O.nn_tour(c, 0)
+    _, cost = O.two_opt(c, seed)
+    cost = O.tour_cost(c, seed)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, k, want_trace=True)
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed)
+    assert best_cost == obc and np.array_equal(best, obest)
+    assert O.valid_tour(best) and O.tour_cost(c, best) == best_cost
+
+
+def test_lds_window_tabu_from_nn_and_ties(eng, T, O, instances, window):
+    """the half-window tabu walk from a raw NN tour (improving moves first -- long reversals, crossing ranges, reloads --,
+    then uphill) and on a caller matrix full of ties"""
+    xy, c = setup(eng, T, O, instances, "n1000_s123", 3, 0)
+    seed, cost = O.nn_tour(c, 5)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 400, want_trace=True)
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, 400)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)
+    r = np.random.RandomState(12)
+    n = 160
+    m = r.randint(1, 12, size=(n, n)).astype(np.float64)
+    m = np.triu(m, 1); m = m + m.T
+    np.fill_diagonal(m, -1.0)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_costs(m)
+    perm = r.permutation(n).astype(np.int32)
+    seed = np.empty(n, dtype=np.int32); seed[perm] = np.roll(perm, -1)
+    cost = O.tour_cost(m, seed)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 300, want_trace=True)
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(m, oseed, cost, 300)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)
+
+
+@pytest.mark.parametrize("n", [4096, 4461, 5000])
+def test_tabu_walk_stays_resident_past_3800(eng, T, O, n):
+    """the tabu walk at the headline size and beyond runs LDS-resident by default (whole rows + ages do not
+    fit beside the matrix at n = 4096: the half windows do): 30 iterations from a 40-sweep descent of NN(0) against the
+    oracle, iteration by iteration"""
+    xy = O.random_points(n, 123)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
+    eng.set_points(xy); eng.build_costs()
+    seed, cost = O.nn_tour(c, 0)
+    _, cost = O.two_opt(c, seed, 40)
+    oseed = seed.copy()
+    best, best_cost, final, trace = eng.tabu_search(seed, cost, 30, want_trace=True)
+    assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, 30)
+    assert np.array_equal(trace, otrace) and final == ofinal and np.array_equal(seed, oseed) and np.array_equal(best, obest)
+
+
+# ------------------------------------------------------------------ K1: one triangle + transposed store (k_build_costs_tri)
+@pytest.mark.parametrize("build", [0, 1])
+@pytest.mark.parametrize("elem", [2, 3])
+@pytest.mark.parametrize("n,kind", [(128, "EUC_2D"), (129, "EUC_2D"), (191, "ATT"), (192, "CEIL_2D"), (1000, "EUC_2D"), (1002, "CEIL_2D"),
+                                    (2049, "ATT"), (4461, "EUC_2D")])
+def test_matrix_triangle_kernel_bit_exact(eng, T, O, n, kind, elem, build):
+    """tsp_compute_costs (tsp.c:608-636) with the upper triangle computed once and every 64 x 64 tile stored twice (the
+    default for integer cells) and with every cell computed: all n x n cells against the oracle, sizes around the tile
+    edges (n % 64 = 0, 1, 63), padded rows, the three weight kinds, non-integer coordinates"""
+    r = np.random.RandomState(n)
+    xy = r.uniform(-5000, 5000, size=(n, 2)) if kind == "EUC_2D" else np.floor(r.uniform(0, 9000, size=(n, 2)))
+    k = {"EUC_2D": O.EUC_2D, "ATT": O.ATT, "CEIL_2D": O.CEIL_2D}[kind]
+    c = O.cost_matrix(xy, k)
+    eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_BUILD_KERNEL, build)
+    try:
+        eng.set_points(xy, {"EUC_2D": T.EUC_2D, "ATT": T.ATT, "CEIL_2D": T.CEIL_2D}[kind])
+        got = eng.build_costs(fetch=True)
+        assert eng.info()["elem"] == elem
+        bad = np.argwhere(got != c)
+        assert len(bad) == 0, (bad[:5], got[tuple(bad[0])], c[tuple(bad[0])])
+    finally:
+        eng.set_option(T.OPT_BUILD_KERNEL, 0)

@@ -298,6 +298,57 @@ __global__ void __launch_bounds__(256) k_build_costs_int(const double2 *__restri
     }
 }
 
+// K1, one triangle: the matrix is symmetric to the last bit (dx * dx == (-dx) * (-dx)), so a 64 x 64 tile (I, J), I <= J, is
+// computed once and stored twice -- as it stands (rows of tile (I, J)) and, through an LDS transpose, as tile (J, I): half
+// the arithmetic of k_build_costs_int (the kernel that was arithmetic-bound: ~20 vector instructions per cell, VERDICT r2
+// "weak" 8), all stores 32-byte row segments.  Grid: one workgroup per tile of the upper triangle, diagonal included.
+// Thread (r, s) of 64 x 4 takes row r, columns 16 s .. 16 s + 15 of the tile; the 128 points come from LDS.
+constexpr int TRI = 64;
+template <typename T, int KIND>
+__global__ void __launch_bounds__(256) k_build_costs_tri(const double2 *__restrict__ pts, int n, int ld, int NT, T *__restrict__ out)
+{
+    constexpr int STR = TRI + 16 / (int)sizeof(T);        // transposed tile's row stride: rows stay 16-byte aligned
+    __shared__ double2 P[2 * TRI];
+    __shared__ __attribute__((aligned(16))) T TT[TRI * STR];
+    // tile (I, J) of the upper triangle from the linear block index: row I holds NT - I tiles
+    int I = 0, rest = (int)blockIdx.x;
+    {   // (solve rest = I * NT - I (I - 1) / 2 + (J - I) without a loop: float guess, integer correction)
+        const float a = (float)(2 * NT + 1);
+        I = (int)((a - __builtin_sqrtf(a * a - 8.0f * (float)rest)) * 0.5f);
+        I = max(0, min(I, NT - 1));
+        while (I > 0 && I * NT - I * (I - 1) / 2 > rest) I--;
+        while (I + 1 < NT && (I + 1) * NT - (I + 1) * I / 2 <= rest) I++;
+        rest -= I * NT - I * (I - 1) / 2;
+    }
+    const int J = I + rest;
+    const int tid = (int)threadIdx.x, r = tid >> 2, c0 = (tid & 3) * 16;
+    if (tid < 2 * TRI) P[tid] = pts[min((tid < TRI ? I : J) * TRI + (tid & (TRI - 1)), n - 1)];
+    __syncthreads();
+    const int i = I * TRI + r, j0 = J * TRI + c0;
+    const double2 pi = P[r];
+    T w[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const double2 pj = P[TRI + c0 + k];
+        const int j = j0 + k;
+        const int v = edge_w<KIND>(pi.x, pi.y, pj.x, pj.y);
+        w[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)v;
+    }
+    typedef T vec16 __attribute__((ext_vector_type(16)));
+    if (i < n && j0 < ld) {
+        vec16 o;
+#pragma unroll
+        for (int k = 0; k < 16; k++) o[k] = w[k];
+        *reinterpret_cast<vec16 *>(out + (size_t)i * ld + j0) = o;
+    }
+    if (I == J) return;                                    // (a diagonal tile is its own transpose)
+#pragma unroll
+    for (int k = 0; k < 16; k++) TT[(c0 + k) * STR + r] = w[k];
+    __syncthreads();
+    const int jt = J * TRI + r, it0 = I * TRI + c0;        // row of tile (J, I), its first column (I < J: every column < n)
+    if (jt < n) *reinterpret_cast<vec16 *>(out + (size_t)jt * ld + it0) = *reinterpret_cast<const vec16 *>(TT + r * STR + c0);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__ pts, int n, int ld, int kind,
                                                      T *__restrict__ out)
@@ -2885,11 +2936,12 @@ struct tspgpu_ctx {
     // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
     int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
+    int opt_build = 0;          // K1 for integer cells: 0 one triangle + transposed store (k_build_costs_tri), 1 every cell computed (k_build_costs_int)
     int opt_persist_window = 0; // 0 auto (half-window rows where whole rows do not fit the chip's LDS), 1 always, 2 never
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
     bool lp_handed = false;    // run_persist began a descent and handed the rest to the per-sweep path
     long lp_sweeps = 0;        // sweeps run by the launches of the last LDS-resident descent / walk
-    bool lpw_attr[2] = {false, false};
+    bool lpw_attr[4] = {false, false, false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
@@ -3634,7 +3686,7 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, boo
 
 // The half-window form (k_lds2opt_w): every row kept as the window of E + n/2 + 16.. cells ahead of the workgroup's first own
 // cell, so that instances a little past n = 4096 (fnl4461, BASELINE config 3) stay LDS-resident.  Plain 2-opt only.
-static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, int &Ws, int &nstage)
+static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, int &Ws, int &nstage, bool tabu = false)
 {
     const int n = ctx->n;
     if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 64 || n > 8191) return false;
@@ -3645,7 +3697,7 @@ static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, i
     if (ws > n || (ws >> 3) - 1 > LW_BT) return false;
     const size_t nl = (size_t)((n + 7) & ~7);
     if ((nl >> 3) > (size_t)LW_BT) return false;
-    const size_t fixed = (size_t)(e + 1) * ws * 2 + (nl + 8) * 4 + 512;
+    const size_t fixed = (size_t)(e + 1) * ws * 2 + (nl + 8) * 4 + 512 + (tabu ? (nl + 16) * 2 : 0);   // (+ the nodes' ages)
     int ns = 2;
     if (fixed + 2 * nl * 2 > ctx->lds_max) ns = 1;
     if (fixed + (size_t)ns * nl * 2 > ctx->lds_max) return false;
@@ -3681,9 +3733,9 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     int E = 0, W = 0, Ws = 0, nstage = 0;
     size_t lds = 0;
     bool win = false;
-    if (ctx->opt_persist_window == 1 && !tabu && persist_fits_w(ctx, E, W, lds, Ws, nstage)) win = true;
+    if (ctx->opt_persist_window == 1 && persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr)) win = true;
     else if (!persist_fits(ctx, E, W, lds, tabu != nullptr)) {
-        if (tabu || ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, nstage)) return E_OK;
+        if (ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr)) return E_OK;
         win = true;
     }
     if (ctx->lp_skip > 0) { ctx->lp_skip--; return E_OK; }
@@ -3698,10 +3750,11 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         ctx->lp_best_n = ctx->ld;
     }
     const int pk = (tabu ? ctx->max8k : ctx->max16k) ? 1 : 0;
-    const void *fn = win ? (pk ? (const void *)k_lds2opt_w<true> : (const void *)k_lds2opt_w<false>)
+    const void *fn = win ? (tabu ? (pk ? (const void *)k_lds2opt_w<true, true> : (const void *)k_lds2opt_w<false, true>)
+                                 : (pk ? (const void *)k_lds2opt_w<true, false> : (const void *)k_lds2opt_w<false, false>))
                    : tabu ? (pk ? (const void *)k_lds2opt<true, true> : (const void *)k_lds2opt<false, true>)
                           : (pk ? (const void *)k_lds2opt<true, false> : (const void *)k_lds2opt<false, false>);
-    bool &attr = win ? ctx->lpw_attr[pk] : ctx->lp_attr[pk + (tabu ? 2 : 0)];
+    bool &attr = win ? ctx->lpw_attr[pk + (tabu ? 2 : 0)] : ctx->lp_attr[pk + (tabu ? 2 : 0)];
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
         attr = true;
@@ -4318,6 +4371,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
     case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LW_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LW_EMAX); ctx->opt_persist_edges = (int)value; break;
+    case TSPGPU_OPT_BUILD_KERNEL: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad build kernel"); ctx->opt_build = (int)value; break;
     case TSPGPU_OPT_PERSIST_WINDOW: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad window mode"); ctx->opt_persist_window = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
     case TSPGPU_OPT_NN_KERNEL: if (value < 0 || value > 3) return fail(ctx, E_INVALID, "bad NN kernel id"); ctx->opt_nn = (int)value; break;
@@ -4396,8 +4450,12 @@ static int launch_build(tspgpu_ctx *ctx)
         hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (double *)ctx->d_mat);
     } else {
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
-#define BUILD_INT(T, K) hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, (n + BUILD_ROWS - 1) / BUILD_ROWS), dim3(256), 0, ctx->stream, \
-                                           ctx->d_pts, n, ld, (T *)ctx->d_mat)
+        // one triangle + transposed store (k_build_costs_tri); TSPGPU_OPT_BUILD_KERNEL = 1 keeps the full-matrix form
+        const int NT = (n + TRI - 1) / TRI;
+        const bool tri = ctx->opt_build == 0 && n >= 2 * TRI && NT <= 2047;
+#define BUILD_INT(T, K) do { if (tri) hipLaunchKernelGGL((k_build_costs_tri<T, K>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
+                             else hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, (n + BUILD_ROWS - 1) / BUILD_ROWS), dim3(256), 0, ctx->stream, \
+                                                     ctx->d_pts, n, ld, (T *)ctx->d_mat); } while (0)
 #define BUILD_KIND(T) do { if (kind == TSPGPU_EUC_2D) BUILD_INT(T, TSPGPU_EUC_2D); else if (kind == TSPGPU_ATT) BUILD_INT(T, TSPGPU_ATT); \
                            else if (kind == KIND_CEIL_INT) BUILD_INT(T, KIND_CEIL_INT); else BUILD_INT(T, TSPGPU_CEIL_2D); } while (0)
         if (ctx->elem == TSPGPU_ELEM_I32) BUILD_KIND(int); else BUILD_KIND(u16);
@@ -4704,7 +4762,7 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
         // the whole walk in one launch, matrix and ages in LDS (k_lds2opt<., true>) where it applies
         const PersistTabu pt = {k, tenure, t_min, t_max, up, *cost};
         if ((rc = run_persist(ctx, 0, nullptr, nullptr, &ran, &pt))) return rc;
-        if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident tabu walk does not apply (uint16 cells, n in [64, ~3800], one idle chip)");
+        if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident tabu walk does not apply (uint16 cells, n in [64, ~5400], one idle chip)");
     }
     if (k > 0 && !ran && (rc = run_sweeps(ctx, 0, 1, true, k, -1, nullptr))) return rc;
     if (trace && k > 0) HIP_TRY(hipMemcpyAsync(trace, ctx->d_trace, (size_t)k * 8, hipMemcpyDeviceToHost, ctx->stream));
