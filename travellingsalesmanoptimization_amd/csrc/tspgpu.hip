@@ -2941,7 +2941,7 @@ struct tspgpu_ctx {
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
     bool lp_handed = false;    // run_persist began a descent and handed the rest to the per-sweep path
     long lp_sweeps = 0;        // sweeps run by the launches of the last LDS-resident descent / walk
-    bool lpw_attr[4] = {false, false, false, false};
+    bool lpw_attr[6] = {false, false, false, false, false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
@@ -2950,7 +2950,7 @@ struct tspgpu_ctx {
     int lp_skip = 0, lp_backoff = 16;   // the grid did not come up co-resident: the next lp_skip descents keep to the one-launch-per-sweep
                                         // path, then it is tried again (16, 32, ... 1024 descents apart while it keeps failing)
     bool lp_used = false;      // the last descent ran in k_lds2opt
-    bool lp_attr[4] = {false, false, false, false};
+    bool lp_attr[6] = {false, false, false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
     bool max8k = false;        // ... <= 8190 (the tabu form of the packed loop: a poisoned pair must exceed every valid delta)
 
@@ -3751,10 +3751,12 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     }
     const int pk = (tabu ? ctx->max8k : ctx->max16k) ? 1 : 0;
     const void *fn = win ? (tabu ? (pk ? (const void *)k_lds2opt_w<true, true> : (const void *)k_lds2opt_w<false, true>)
+                                 : vns ? (pk ? (const void *)k_lds2opt_w<true, false, true> : (const void *)k_lds2opt_w<false, false, true>)
                                  : (pk ? (const void *)k_lds2opt_w<true, false> : (const void *)k_lds2opt_w<false, false>))
+                   : vns ? (pk ? (const void *)k_lds2opt<true, false, true> : (const void *)k_lds2opt<false, false, true>)
                    : tabu ? (pk ? (const void *)k_lds2opt<true, true> : (const void *)k_lds2opt<false, true>)
                           : (pk ? (const void *)k_lds2opt<true, false> : (const void *)k_lds2opt<false, false>);
-    bool &attr = win ? ctx->lpw_attr[pk + (tabu ? 2 : 0)] : ctx->lp_attr[pk + (tabu ? 2 : 0)];
+    bool &attr = win ? ctx->lpw_attr[pk + (tabu ? 2 : vns ? 4 : 0)] : ctx->lp_attr[pk + (tabu ? 2 : vns ? 4 : 0)];
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
         attr = true;
