@@ -74,8 +74,9 @@ enum {
                                    co-resident --, 2 or fail with code 8 */
     TSPGPU_OPT_PERSIST_EDGES = 17, /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16 with whole
                                    rows, 24 with half-window rows) */
-    TSPGPU_OPT_BUILD_KERNEL = 19,  /* tspgpu_build_costs with integer cells: 0 (default) the upper triangle computed once, every
-                                   64 x 64 tile stored twice (as it is and transposed through LDS), 1 every cell computed */
+    TSPGPU_OPT_BUILD_KERNEL = 19,  /* tspgpu_build_costs with uint16 cells: 0 (default) the upper triangle computed once, every
+                                   64 x 64 tile stored twice (as it is and transposed through LDS), 1 every cell computed
+                                   (what int32 / f64 cells always do) */
     TSPGPU_OPT_PERSIST_WINDOW = 18 /* rows of that kernel: 0 auto (whole rows where they fit the chip's LDS, else the half
                                    window of n/2 cells ahead of the workgroup's own edges), 1 half-window rows wherever they
                                    apply, 2 whole rows only */

@@ -1579,7 +1579,7 @@ def test_tabu_walk_stays_resident_past_3800(eng, T, O, n):
                                     (2049, "ATT"), (4461, "EUC_2D")])
 def test_matrix_triangle_kernel_bit_exact(eng, T, O, n, kind, elem, build):
     """tsp_compute_costs (tsp.c:608-636) with the upper triangle computed once and every 64 x 64 tile stored twice (the
-    default for integer cells) and with every cell computed: all n x n cells against the oracle, sizes around the tile
+    default for uint16 cells) and with every cell computed: all n x n cells against the oracle, sizes around the tile
     edges (n % 64 = 0, 1, 63), padded rows, the three weight kinds, non-integer coordinates"""
     r = np.random.RandomState(n)
     xy = r.uniform(-5000, 5000, size=(n, 2)) if kind == "EUC_2D" else np.floor(r.uniform(0, 9000, size=(n, 2)))

@@ -244,7 +244,9 @@ __device__ __forceinline__ typename Elem<T>::acc cell(const T *mat, const double
 // exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
 // the f32 root (within 1 of the floor) and is corrected with exact f64 products.
 constexpr int KIND_CEIL_INT = 3;
-template <int KIND>
+// F32R (EUC_2D only): the final (int)((double)root + 0.5) in f32 -- exact while the root is below 2^22 (root + 0.5f is then
+// representable: 0.5 is a multiple of the root's ulp), three f64 conversions / additions less per weight
+template <int KIND, bool F32R = false>
 __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
 {
     const double dx = bx - ax, dy = by - ay;
@@ -256,6 +258,7 @@ __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by
         const float em = __builtin_fmaf(-rm, r, x), ep = __builtin_fmaf(-rp, r, x);
         float c = 0.0f >= em ? rm : r;
         c = 0.0f < ep ? rp : c;
+        if constexpr (F32R) return (int)(c + 0.5f);
         return (int)((double)c + 0.5);
     } else if constexpr (KIND == KIND_CEIL_INT) {
         double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
@@ -304,7 +307,7 @@ __global__ void __launch_bounds__(256) k_build_costs_int(const double2 *__restri
 // "weak" 8), all stores 32-byte row segments.  Grid: one workgroup per tile of the upper triangle, diagonal included.
 // Thread (r, s) of 64 x 4 takes row r, columns 16 s .. 16 s + 15 of the tile; the 128 points come from LDS.
 constexpr int TRI = 64;
-template <typename T, int KIND>
+template <typename T, int KIND, bool F32R>
 __global__ void __launch_bounds__(256) k_build_costs_tri(const double2 *__restrict__ pts, int n, int ld, int NT, T *__restrict__ out)
 {
     constexpr int STR = TRI + 16 / (int)sizeof(T);        // transposed tile's row stride: rows stay 16-byte aligned
@@ -327,12 +330,21 @@ __global__ void __launch_bounds__(256) k_build_costs_tri(const double2 *__restri
     const int i = I * TRI + r, j0 = J * TRI + c0;
     const double2 pi = P[r];
     T w[16];
+    const bool inner = I != J && (J + 1) * TRI <= n;      // no diagonal cell, no column past n: no masks (workgroup-uniform)
+    if (inner) {
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const double2 pj = P[TRI + c0 + k];
-        const int j = j0 + k;
-        const int v = edge_w<KIND>(pi.x, pi.y, pj.x, pj.y);
-        w[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)v;
+        for (int k = 0; k < 16; k++) {
+            const double2 pj = P[TRI + c0 + k];
+            w[k] = (T)edge_w<KIND, F32R>(pi.x, pi.y, pj.x, pj.y);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const double2 pj = P[TRI + c0 + k];
+            const int j = j0 + k;
+            const int v = edge_w<KIND, F32R>(pi.x, pi.y, pj.x, pj.y);
+            w[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)v;
+        }
     }
     typedef T vec16 __attribute__((ext_vector_type(16)));
     if (i < n && j0 < ld) {
@@ -2943,6 +2955,7 @@ struct tspgpu_ctx {
     long lp_sweeps = 0;        // sweeps run by the launches of the last LDS-resident descent / walk
     bool lpw_attr[6] = {false, false, false, false, false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
+    int opt_lp_poll_sleep = 0;  // probe hook 95
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
     int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk / VNS: the best tour by array cell [ld], its direction and flag [2]
@@ -3816,6 +3829,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         A.hello_ticks = ctx->opt_lp_hello;   // 2 ms (test hook 97: negative = workgroup 0 withholds its record for that long)
         if (ctx->opt_lp_fail_at > 0 && !first) { ctx->opt_lp_fail_at--; A.hello_ticks = -5000; }   // test hook 96: the next N relaunches fail their rendezvous
         A.spin_ticks = 100000000;      // 1 s
+        A.poll_sleep = ctx->opt_lp_poll_sleep;
         A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
         if (tabu) {
             A.budget = -1;
@@ -4361,6 +4375,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 95: ctx->opt_lp_poll_sleep = (int)value; break; // undocumented: s_sleep(1) repetitions between polls of the exchange slots (tools/persist_probe.py)
     case 96: ctx->opt_lp_fail_at = (int)value; break; // undocumented: see opt_lp_fail_at (tests)
     case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_skip = 0; ctx->lp_backoff = 16; break; // undocumented: rendezvous limit of k_lds2opt (tests)
     case 98: // undocumented: per-workgroup phase stamps of the pipelined sweep (single tour)
@@ -4454,8 +4469,12 @@ static int launch_build(tspgpu_ctx *ctx)
         const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
         // one triangle + transposed store (k_build_costs_tri); TSPGPU_OPT_BUILD_KERNEL = 1 keeps the full-matrix form
         const int NT = (n + TRI - 1) / TRI;
-        const bool tri = ctx->opt_build == 0 && n >= 2 * TRI && NT <= 2047;
-#define BUILD_INT(T, K) do { if (tri) hipLaunchKernelGGL((k_build_costs_tri<T, K>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
+        // (uint16 cells only: with int32 cells the 64-byte row segments of the transposed tiles store slower than the
+        // arithmetic they save -- measured 27.5 vs 16.7 us at n=4096, tools/build_probe.py)
+        const bool tri = ctx->opt_build == 0 && ctx->elem == TSPGPU_ELEM_U16 && n >= 2 * TRI && NT <= 2047;
+        const bool f32r = kind == TSPGPU_EUC_2D && ctx->cost_bound < 4.0e6;      // (every root below 2^22)
+#define BUILD_INT(T, K) do { if (tri && f32r && K == TSPGPU_EUC_2D) hipLaunchKernelGGL((k_build_costs_tri<T, TSPGPU_EUC_2D, true>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
+                             else if (tri) hipLaunchKernelGGL((k_build_costs_tri<T, K, false>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
                              else hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, (n + BUILD_ROWS - 1) / BUILD_ROWS), dim3(256), 0, ctx->stream, \
                                                      ctx->d_pts, n, ld, (T *)ctx->d_mat); } while (0)
 #define BUILD_KIND(T) do { if (kind == TSPGPU_EUC_2D) BUILD_INT(T, TSPGPU_EUC_2D); else if (kind == TSPGPU_ATT) BUILD_INT(T, TSPGPU_ATT); \
