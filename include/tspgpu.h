@@ -202,6 +202,10 @@ enum { TSPGPU_MOPT_EXCHANGE = 1000 };   /* tspgpu_multi_set_option: 0 auto (RCCL
                                            G = 1, host for a repeated device), 1 host, 2 RCCL (also with G = 1: a
                                            one-rank communicator; refused for a repeated device).  Every other option
                                            is a TSPGPU_OPT_* applied to each device's context. */
+/* the winner among G per-device results by the host exchange's order (by_keys = 0) or by the keys the RCCL exchange reduces
+ * (by_keys = 1); pos[i] < 0 = device i found nothing; returns the device rank, -1 if nobody, -2 on a bad argument.  Pure
+ * host arithmetic (no device needed): what pins both selection orders in the CPU tests. */
+int  tspgpu_multi_select(const double *cost, const long *pos, int ndev, int by_keys);
 int  tspgpu_multi_create(const int *device_ids, int ndev, tspgpu_multi **out);
 void tspgpu_multi_destroy(tspgpu_multi *m);
 const char *tspgpu_multi_last_error(const tspgpu_multi *m);

@@ -2,7 +2,7 @@
 """debug: cost returned by tspgpu_two_opt (one launch per sweep) vs the tour's cost, on kicked tours of a large instance"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as O
 import travellingsalesmanoptimization_amd as T

@@ -2,7 +2,7 @@
 """debug: the descent from the kicked tour of iteration 63 (fnl4461) under several kernel configurations vs the oracle"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as O
 import travellingsalesmanoptimization_amd as T

@@ -2,7 +2,7 @@
 """debug: VNS traces resident vs host-kicks vs oracle on a large instance"""
 import ctypes, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import oracle as O
 name, k = sys.argv[1], int(sys.argv[2])

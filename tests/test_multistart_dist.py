@@ -111,6 +111,42 @@ def test_pack_key_and_sharding():
     assert (c, st) == (5.0, 3)
 
 
+def test_c_driver_selection_orders_agree():
+    """the RCCL path of the C multi-device driver (csrc/tspgpu_multi.cpp) has only ever run on one rank.  Its
+    selection is pure arithmetic on the keys the devices reduce with ncclMin -- one packed int64, or, for costs that do not
+    pack (fractional, >= 2^31, list position >= 2^24), the cost's IEEE bit pattern and then position | rank --:
+    tspgpu_multi_select computes those keys on the host (no device) and must pick the same winner as the host exchange's
+    (cost, position, rank) order, ties and empty devices included"""
+    sys.path.insert(0, ROOT)
+    import travellingsalesmanoptimization_amd as T
+    L = T._lib.load()
+    rng = np.random.default_rng(5)
+
+    def both(cost, pos):
+        cost = np.ascontiguousarray(cost, dtype=np.float64); pos = np.ascontiguousarray(pos, dtype=np.int64)
+        a = L.tspgpu_multi_select(cost, pos, len(cost), 0)
+        b = L.tspgpu_multi_select(cost, pos, len(cost), 1)
+        assert a == b, (cost, pos, a, b)
+        return a
+
+    assert both([7657.0, 7657.0, 7700.0], [51, 12, 0]) == 1                    # tie on the cost: the earliest list position
+    assert both([5.0, 4.0, 4.0, 9.0], [3, -1, 8, 1]) == 2                      # a device that found nothing never wins
+    assert both([1.0, 2.0], [-1, -1]) == -1
+    assert both([1121.03, 1121.02, 1121.03], [0, 9, 1]) == 1                   # fractional costs: the bit-pattern branch
+    assert both([2.0 ** 31, 2.0 ** 31 + 1, 2.0 ** 31], [7, 0, 3]) == 2          # costs >= 2^31 do not pack; tie -> position 3 < 7
+    assert both([10.0, 10.0], [2 ** 24 + 5, 2 ** 24 + 1]) == 1                 # positions >= 2^24 do not pack
+    assert both([0.0, 0.0, 0.0], [2, 1, 1]) in (1, 2)                          # (equal cost and position cannot happen: a start lives on one device)
+    for _ in range(300):
+        G = int(rng.integers(1, 9))
+        kind = rng.integers(0, 4)
+        base = [1000.0, 1000.5, 2.0 ** 31 + 10, 1e15][kind]
+        cost = base + rng.integers(0, 4, size=G) * (0.25 if kind == 1 else 1.0)
+        pos = rng.permutation(64)[:G].astype(np.int64) + (2 ** 24 if rng.integers(0, 5) == 0 else 0)
+        pos[rng.random(G) < 0.2] = -1
+        both(cost, pos)
+    assert L.tspgpu_multi_select(np.array([-1.0]), np.array([0], dtype=np.int64), 1, 1) in (0, -2)   # (a negative cost: refused or packed away)
+
+
 # ---------------------------------------------------------------------------
 # intra-sweep sharding: two ranks share ONE GPU (gloo for the 8-byte key), each evaluates half of
 # the runs of every sweep; the trajectory must be the single-GPU one

@@ -55,6 +55,7 @@ SIGNATURES = {
     "tspgpu_nn_all_timed": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pi]),
     "tspgpu_multistart_nn_2opt": (C.c_int, [_ctx, C.c_void_p, C.c_int, C.c_double, _ip, _pd, _pi, _pl,
                                             C.c_void_p, C.c_void_p]),
+    "tspgpu_multi_select": (C.c_int, [_dp, np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS"), C.c_int, C.c_int]),
     "tspgpu_multi_create": (C.c_int, [_ip, C.c_int, C.POINTER(_ctx)]),
     "tspgpu_multi_destroy": (None, [_ctx]),
     "tspgpu_multi_last_error": (C.c_char_p, [_ctx]),

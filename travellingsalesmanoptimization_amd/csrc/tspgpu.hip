@@ -4796,7 +4796,7 @@ int tspgpu_tabu_search(tspgpu_ctx *ctx, int *path, double *cost, int k, int *bes
 }
 
 // host side of vns_kick (metaheuristic.c:344-409, :490-500) for the non-resident path of tspgpu_vns_search: the same
-// draws, the same rejection rule, the same unwrapped probes as tspgpu_lds_vns.inc (and as oracle/cpu_ref.c models them)
+// draws, the same rejection rule, the same unwrapped probes as tspgpu_lds_vns.inc
 static bool vns_kick_host(std::vector<int> &succ, std::vector<int> &tour, const int *rv, long nrand, long &cur)
 {
     const int n = (int)succ.size();

@@ -69,6 +69,31 @@ long long pack_key(double cost, long pos, int rank)
     return (c << 32) | ((long long)pos << 8) | rank;
 }
 
+// The keys the devices reduce with ncclMin, as pure host arithmetic (tspgpu_multi_select runs the same functions without
+// a device: tests/test_multistart_dist.py pins both selection orders on the CPU).
+// stage 1: the packed key where every local result packs, else the cost's IEEE bit pattern (a non-negative double orders
+// like its bits); KEY_NONE for a device that found nothing.  Returns false when some cost is negative.
+bool stage1_keys(const double *cost, const long *pos, int G, long long *key, bool *packs)
+{
+    *packs = true;
+    for (int i = 0; i < G; i++) {
+        key[i] = pos[i] < 0 ? KEY_NONE : pack_key(cost[i], pos[i], i);
+        if (key[i] < 0) *packs = false;
+    }
+    if (*packs) return true;
+    for (int i = 0; i < G; i++) {
+        long long bits = KEY_NONE;
+        if (pos[i] >= 0) { if (cost[i] < 0) return false; memcpy(&bits, &cost[i], 8); }
+        key[i] = bits;
+    }
+    return true;
+}
+// stage 2 (unpackable costs only): among the devices that hold the minimum cost, earliest list position, then rank
+void stage2_keys(const long *pos, int G, long long cmin, long long *key)
+{
+    for (int i = 0; i < G; i++) key[i] = (pos[i] >= 0 && key[i] == cmin) ? ((long long)pos[i] << 8) | i : KEY_NONE;
+}
+
 } // namespace
 
 struct tspgpu_multi {
@@ -225,26 +250,21 @@ int exchange(tspgpu_multi *m, std::vector<Local> &L, int n, int *best_path, doub
     if (kind == 2) {
         int rc;
         std::vector<long long> key(G);
+        std::vector<double> lc(G);
+        std::vector<long> lp(G);
+        for (int i = 0; i < G; i++) { lc[i] = L[i].cost; lp[i] = L[i].pos; }
         bool packs = true;
-        for (int i = 0; i < G; i++) {
-            key[i] = L[i].pos < 0 ? KEY_NONE : pack_key(L[i].cost, L[i].pos, i);
-            if (key[i] < 0) packs = false;
-        }
+        if (!stage1_keys(lc.data(), lp.data(), G, key.data(), &packs)) return mfail(m, E_INTERNAL, "negative tour cost");
         long long kmin = KEY_NONE;
         if (packs) {
             if ((rc = allreduce_min(m, key, &kmin))) return rc;            // the one MIN all-reduce
             if (kmin != KEY_NONE) win = (int)(kmin & 0xff);
         } else {
             // costs that do not fit 31 bits: the IEEE bit pattern of a non-negative double orders like the value
-            for (int i = 0; i < G; i++) {
-                long long bits = KEY_NONE;
-                if (L[i].pos >= 0) { if (L[i].cost < 0) return mfail(m, E_INTERNAL, "negative tour cost %g", L[i].cost); memcpy(&bits, &L[i].cost, 8); }
-                key[i] = bits;
-            }
             long long cmin = KEY_NONE;
             if ((rc = allreduce_min(m, key, &cmin))) return rc;
             if (cmin != KEY_NONE) {
-                for (int i = 0; i < G; i++) key[i] = (L[i].pos >= 0 && key[i] == cmin) ? ((long long)L[i].pos << 8) | i : KEY_NONE;
+                stage2_keys(lp.data(), G, cmin, key.data());
                 if ((rc = allreduce_min(m, key, &kmin))) return rc;
                 win = (int)(kmin & 0xff);
             }
@@ -292,6 +312,31 @@ template <typename F> int per_device(tspgpu_multi *m, F fn)
 } // namespace
 
 extern "C" {
+
+// The winner among G local results (cost[i], pos[i]; pos < 0: device i found nothing).  by_keys = 0: the host exchange's
+// order (lowest cost, then earliest list position, then lowest rank); 1: the minimum of the keys the RCCL exchange reduces
+// (one packed int64 per device, or -- a cost that is fractional, >= 2^31, or a position >= 2^24 -- the cost's bit pattern,
+// then position | rank among the holders of the minimum).  Pure host arithmetic: no device, no RCCL.  -1: nobody.
+int tspgpu_multi_select(const double *cost, const long *pos, int G, int by_keys)
+{
+    if (!cost || !pos || G <= 0 || G > 256) return -2;
+    int win = -1;
+    if (!by_keys) {
+        for (int i = 0; i < G; i++)
+            if (pos[i] >= 0 && (win < 0 || cost[i] < cost[win] || (cost[i] == cost[win] && pos[i] < pos[win]))) win = i;
+        return win;
+    }
+    std::vector<long long> key(G);
+    bool packs = true;
+    if (!stage1_keys(cost, pos, G, key.data(), &packs)) return -2;
+    long long kmin = *std::min_element(key.begin(), key.end());           // (what ncclAllReduce(ncclMin) leaves everywhere)
+    if (kmin == KEY_NONE) return -1;
+    if (packs) return (int)(kmin & 0xff);
+    stage2_keys(pos, G, kmin, key.data());
+    kmin = *std::min_element(key.begin(), key.end());
+    return (int)(kmin & 0xff);
+}
+
 
 int tspgpu_multi_create(const int *device_ids, int ndev, tspgpu_multi **out)
 {

@@ -26,6 +26,9 @@
 typedef struct thread_ctx {
     tspgpu_ctx *gpu;
     struct thread_ctx *next;
+    pthread_mutex_t use;        /* held by the owning thread for the duration of a device call, and by whoever destroys
+                                   the context: tsp_gpu_release_threads() waits for a call in flight instead of freeing
+                                   the context under it */
 } thread_ctx;
 
 static pthread_mutex_t reg_lock = PTHREAD_MUTEX_INITIALIZER;
@@ -43,10 +46,14 @@ static void reg_unlink(thread_ctx *t)
 static void thread_ctx_exit(void *arg)          /* runs in the exiting thread */
 {
     thread_ctx *t = (thread_ctx *)arg;
-    pthread_mutex_lock(&reg_lock);
+    pthread_mutex_lock(&reg_lock);              /* (tsp_gpu_release_threads walks the list under this lock) */
     reg_unlink(t);
     pthread_mutex_unlock(&reg_lock);
+    pthread_mutex_lock(&t->use);
     tspgpu_destroy(t->gpu);
+    t->gpu = NULL;
+    pthread_mutex_unlock(&t->use);
+    pthread_mutex_destroy(&t->use);
     free(t);
 }
 
@@ -60,35 +67,43 @@ int tsp_gpu_thread_contexts(void)
     return live;
 }
 
-/* destroys the contexts of threads that are still alive; they re-create theirs on the next call */
+/* destroys the contexts of threads that are still alive (waiting for a device call that one of them may be in); they
+ * re-create theirs on the next call */
 void tsp_gpu_release_threads(void)
 {
     pthread_mutex_lock(&reg_lock);
     for (thread_ctx *t = reg_head; t; t = t->next) {
+        pthread_mutex_lock(&t->use);
         if (t->gpu) tspgpu_destroy(t->gpu);
         t->gpu = NULL;
+        pthread_mutex_unlock(&t->use);
     }
     pthread_mutex_unlock(&reg_lock);
 }
 
-static tspgpu_ctx *thread_gpu(void)
+/* the calling thread's context, LOCKED (thread_done() when the device call is over); NULL without a device */
+static thread_ctx *thread_lease(void)
 {
     pthread_once(&reg_once, reg_make_key);
     thread_ctx *t = (thread_ctx *)pthread_getspecific(reg_key);
     if (!t) {
         t = (thread_ctx *)calloc(1, sizeof *t);
         if (!t) return NULL;
+        pthread_mutex_init(&t->use, NULL);
         pthread_setspecific(reg_key, t);
         pthread_mutex_lock(&reg_lock);
         t->next = reg_head; reg_head = t; reg_live++;
         pthread_mutex_unlock(&reg_lock);
     }
+    pthread_mutex_lock(&t->use);
     if (!t->gpu) {
         const char *dev = getenv("TSP_GPU_DEVICE");
-        if (tspgpu_create(dev ? atoi(dev) : 0, &t->gpu) != 0) { t->gpu = NULL; return NULL; }
+        if (tspgpu_create(dev ? atoi(dev) : 0, &t->gpu) != 0) { t->gpu = NULL; pthread_mutex_unlock(&t->use); return NULL; }
     }
-    return t->gpu;
+    return t;
 }
+
+static void thread_done(thread_ctx *t) { if (t) pthread_mutex_unlock(&t->use); }
 
 static double time_left(void)
 {
@@ -105,16 +120,19 @@ static bool past_deadline(void)
 /* Context holding `costs`.  The instance's own matrix lives in the process-wide context; any other pointer is a
  * caller matrix and is uploaded into the calling thread's context on EVERY call: the pointer says nothing about
  * the contents (cplex_model.c:1176-1258 refills one buffer per callback), so nothing is cached across calls. */
-static tspgpu_ctx *ctx_for(double *costs)
+static tspgpu_ctx *ctx_for(double *costs, thread_ctx **lease)
 {
+    *lease = NULL;
     if (costs == tsp_inst.costs || (!costs && tsp_lazy_costs)) return tsp_gpu();
-    tspgpu_ctx *g = thread_gpu();
-    if (!g) return NULL;
-    if (tspgpu_set_costs(g, costs, tsp_inst.nnodes) != 0) {
-        log_error("tspgpu_set_costs: %s", tspgpu_last_error(g));
+    thread_ctx *t = thread_lease();
+    if (!t) return NULL;
+    if (tspgpu_set_costs(t->gpu, costs, tsp_inst.nnodes) != 0) {
+        log_error("tspgpu_set_costs: %s", tspgpu_last_error(t->gpu));
+        thread_done(t);
         return NULL;
     }
-    return g;
+    *lease = t;                                 /* held until thread_done(): the context cannot be destroyed under the call */
+    return t->gpu;
 }
 
 static ERROR_CODE from_rc(int rc) { return (ERROR_CODE)rc; }
@@ -138,7 +156,8 @@ static void multi_stats(const char *what, struct tspgpu_multi *m, int starts, lo
  * (tspgpu_two_opt); the deadline is polled once per batch of sweeps instead of per sweep. */
 ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent)
 {
-    tspgpu_ctx *g = ctx_for(costs);
+    thread_ctx *lease;
+    tspgpu_ctx *g = ctx_for(costs, &lease);
     if (!g) return UNAVAILABLE;
     ERROR_CODE e = T_OK;
     if (past_deadline()) {
@@ -153,10 +172,12 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
         int rc = tspgpu_two_opt(g, solution->path, &solution->cost, time_left(), NULL);
         if (rc != 0 && rc != DEADLINE_EXCEEDED) {
             log_error("tspgpu_two_opt: %s", tspgpu_last_error(g));
+            thread_done(lease);
             return from_rc(rc);
         }
         e = from_rc(rc);
     }
+    thread_done(lease);
     if (update_incumbent) {
         ERROR_CODE u = tsp_update_best_solution(solution);
         if (!err_ok(u)) log_error("code %d : Error in 2opt solution update", u);
@@ -169,12 +190,15 @@ ERROR_CODE ref_2opt(tsp_solution *solution, double *costs, bool update_incumbent
  * would make a caller that loops on the delta stop as if it had reached a local optimum. */
 double ref_2opt_once(tsp_solution *solution, double *costs)
 {
-    tspgpu_ctx *g = ctx_for(costs);
+    thread_ctx *lease;
+    tspgpu_ctx *g = ctx_for(costs, &lease);
     double delta = 0;
     if (!g || tspgpu_two_opt_once(g, solution->path, &solution->cost, &delta) != 0) {
         log_fatal("tspgpu_two_opt_once failed: %s", g ? tspgpu_last_error(g) : "no device");
+        thread_done(lease);
         tsp_handlefatal();
     }
+    thread_done(lease);
     return delta;
 }
 
@@ -200,10 +224,12 @@ ERROR_CODE h_greedyutil(int starting_node, tsp_solution *solution, double *costs
     if (!costs && !tsp_matrix_free && !tsp_lazy_costs) { log_error("matrix of costs not found"); return INTERNAL; }
     if (starting_node >= tsp_inst.nnodes || starting_node < 0) { log_error("starting node not correct"); return UNAVAILABLE; }
     if (past_deadline()) { log_warn("time limit exceeded in greedy util"); return DEADLINE_EXCEEDED; }
-    tspgpu_ctx *g = ctx_for(costs);
+    thread_ctx *lease;
+    tspgpu_ctx *g = ctx_for(costs, &lease);
     if (!g) return UNAVAILABLE;
     int rc = tspgpu_nn_tour(g, starting_node, solution->path, &solution->cost);
     if (rc) log_error("tspgpu_nn_tour: %s", tspgpu_last_error(g));
+    thread_done(lease);
     return from_rc(rc);
 }
 
@@ -288,7 +314,8 @@ ERROR_CODE h_greedy_2opt(void)
 ERROR_CODE h_Greedy_2opt_mod_costs(tsp_solution *solution, double *costs)
 {
     if (past_deadline()) return DEADLINE_EXCEEDED;
-    tspgpu_ctx *g = ctx_for(costs);
+    thread_ctx *lease;
+    tspgpu_ctx *g = ctx_for(costs, &lease);
     if (!g) return UNAVAILABLE;
     const int n = tsp_inst.nnodes;
     int *best = (int *)malloc((size_t)n * sizeof(int));
@@ -297,6 +324,7 @@ ERROR_CODE h_Greedy_2opt_mod_costs(tsp_solution *solution, double *costs)
     int rc = tspgpu_multistart_nn_2opt(g, NULL, n, time_left(), best, &best_cost, &start, NULL, solution->path, &solution->cost);
     free(best);
     if (rc != 0 && rc != DEADLINE_EXCEEDED) log_error("tspgpu_multistart_nn_2opt: %s", tspgpu_last_error(g));
+    thread_done(lease);
     return from_rc(rc);
 }
 
