@@ -532,3 +532,36 @@ def test_host_tabu_search_other_policies(host, O, policy, tenure_of):
     assert inst.best_solution.cost == bc
     assert np.array_equal(np.ctypeslib.as_array(inst.best_solution.path, shape=(n,)), best)
     host.tsp_free_instance()
+
+
+@pytest.mark.gpu
+def test_host_lazy_costs(host, O, golden):
+    """tsp_lazy_costs (what the `tsp` executable runs with): tsp_compute_costs builds the matrix on the device only,
+    tsp_inst.costs stays NULL -- the heuristic entry points take it as "the instance's matrix" --, and the first tsp_get_cost
+    downloads it; the same results as with the eager copy"""
+    import numpy as np
+    lazy = C.c_bool.in_dll(host, "tsp_lazy_costs")
+    host.tsp_get_cost.restype = C.c_double
+    host.tsp_get_cost.argtypes = [C.c_int, C.c_int]
+    host.h_greedyutil.argtypes = [C.c_int, C.POINTER(Solution), C.c_void_p]
+    host.ref_2opt.argtypes = [C.POINTER(Solution), C.c_void_p, C.c_bool]
+    host.tsp_init_solution.argtypes = [C.c_int, C.POINTER(Solution)]
+    lazy.value = True
+    try:
+        tenv, inst = _host_instance(host, "pr1002")
+        n = inst.nnodes
+        assert not inst.costs                                   # nothing on the host yet
+        g = golden["instances"]["pr1002"]["two_opt"]
+        sol = Solution()
+        assert host.tsp_init_solution(n, C.byref(sol)) == 0
+        assert host.h_greedyutil(0, C.byref(sol), inst.costs) == 0 and sol.cost == g["nn_cost"]
+        assert host.ref_2opt(C.byref(sol), inst.costs, False) == 0 and sol.cost == g["final_cost"]
+        assert not inst.costs                                   # the whole heuristic path ran without a host matrix
+        xy, _ = O.read_tsplib(os.path.join(DATA, "pr1002.tsp"))
+        c = O.cost_matrix(xy)
+        assert host.tsp_get_cost(3, 977) == c[3, 977] and inst.costs    # first read: downloaded
+        got = np.ctypeslib.as_array(C.cast(inst.costs, C.POINTER(C.c_double)), shape=(n, n))
+        assert np.array_equal(got, c)
+    finally:
+        lazy.value = False
+        host.tsp_free_instance()
