@@ -565,3 +565,19 @@ def test_host_lazy_costs(host, O, golden):
     finally:
         lazy.value = False
         host.tsp_free_instance()
+
+
+@pytest.mark.gpu
+def test_binary_walks_at_resident_sizes_against_the_compiled_reference():
+    """whole metaheuristic runs of the compiled reference at the sizes the device-resident loops take
+    (tests/golden/golden_walks.json, oracle/make_golden_walks.py: `-alg VNS -k 200` and `-alg TABU_SEARCH -k 200` on pr1002 --
+    whole-row LDS kernel --, `-alg VNS -k 12` on fnl4461 -- BASELINE config 3's instance under config 5's algorithm, half-window
+    kernel): the `tsp` binary prints the reference's cost"""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_walks.json")))["runs"]
+    assert "pr1002_vns_k200" in g
+    for key, r in g.items():
+        alg = {3: "TABU_SEARCH", 4: "VNS"}[r["alg"]]
+        rc, out, err = run_q("-f", os.path.join(DATA, r["instance"] + ".tsp"), "-alg", alg, "-k", str(r["k"]))
+        assert rc == 0, (key, err[-500:])
+        assert out == "Cost: %.2f" % r["cost"], (key, out)
