@@ -96,7 +96,8 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * edges per workgroup and LDS bytes per workgroup of that kernel on this instance (0: it does not apply), 19 window cells per
  * row of its half-window form (0: whole rows), 20 the last single-tour descent ran in the half-window form, 21 the last
  * single-tour descent began LDS-resident and was finished one launch per sweep (the grid lost its co-residency), 22 sweeps run by the last
- * LDS-resident descent / tabu walk / VNS walk */
+ * LDS-resident descent / tabu walk / VNS walk, 23 how the last tspgpu_vns_search ran (1 resident throughout, 2 one device local
+ * search per iteration with the kicks on the host, 3 resident launches first, then -- the grid lost its co-residency -- host kicks) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

@@ -1594,3 +1594,28 @@ def test_matrix_triangle_kernel_bit_exact(eng, T, O, n, kind, elem, build):
         assert len(bad) == 0, (bad[:5], got[tuple(bad[0])], c[tuple(bad[0])])
     finally:
         eng.set_option(T.OPT_BUILD_KERNEL, 0)
+
+
+def test_vns_search_relaunches_and_grid_loss(T, O, instances):
+    """the resident VNS walk in launches of 7 iterations (test hook 94) equals the oracle's walk; and when the grid loses its
+    co-residency after the first launch (hook 96: the next four launches fail their rendezvous) the walk goes on with one
+    device local search per iteration and the kicks on the host from the tour, incumbent, iteration and stream position the
+    last completed launch left -- same result, same number of rand() values consumed"""
+    e = T.Engine(0)
+    try:
+        xy, c = instances("n200_s3")
+        e.set_option(T.OPT_ELEM, 3); e.set_points(xy); e.build_costs()
+        k = 60
+        seed0, cost0 = O.nn_tour(c, 3)
+        rv = _libc_draws(O, 11, 64 * k + 4096)
+        obest, obc, ofinal, oused = _oracle_vns(O, c, seed0, cost0, k, 11, rv)
+        for fail in (0, 4):
+            e.set_option(94, 7); e.set_option(96, fail); e.set_option(T.OPT_PERSIST, 1)
+            path, best = seed0.copy(), seed0.copy()
+            r = e.vns_search(path, k, rv, best, cost0, want_trace=True)
+            assert (r["rc"], r["iterations"], r["kick_pending"]) == (0, k, 0)
+            assert e.info()["vns_mode"] == (3 if fail else 1)
+            assert r["best_cost"] == obc and np.array_equal(best, obest) and np.array_equal(path, ofinal) and r["consumed"] == oused
+            assert not np.isnan(r["trace"]).any() and r["trace"].min() == obc
+    finally:
+        e.close()

@@ -2953,9 +2953,12 @@ struct tspgpu_ctx {
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
     bool lp_handed = false;    // run_persist began a descent and handed the rest to the per-sweep path
     long lp_sweeps = 0;        // sweeps run by the launches of the last LDS-resident descent / walk
+    int vns_mode = 0;          // the last tspgpu_vns_search: 1 resident throughout, 2 host kicks throughout, 3 resident launches first,
+                               // then (the grid lost its co-residency) host kicks
     bool lpw_attr[6] = {false, false, false, false, false, false};
     long opt_lp_hello = 200000; // rendezvous limit in 10 ns ticks
     int opt_lp_poll_sleep = 0;  // probe hook 95
+    int opt_vns_launch_k = 65536;   // VNS iterations a launch may complete (test hook 94 lowers it to force relaunches)
     int opt_lp_fail_at = 0;     // test hook 96: the next N RE-launches of a descent (deadline runs relaunch per sweep budget) fail their rendezvous
     u64 *d_lp_slots = nullptr; int *h_lp = nullptr;   // (the control words sit behind the slots)
     int *d_lp_best = nullptr; int lp_best_n = 0;      // tabu walk / VNS: the best tour by array cell [ld], its direction and flag [2]
@@ -3803,7 +3806,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         if (vns) {
             // this launch: at most 65536 iterations, the numbers they can be expected to need (a kick phase draws 1 + 3 per
             // kick + the rejected ones, 8 on average; the kernel stops in front of a kick phase it cannot finish)
-            vns_launch_k = std::min(vns->k - vns->it, 65536);
+            vns_launch_k = std::min(vns->k - vns->it, ctx->opt_vns_launch_k);
             const long want = std::min<long>(vns->nrand - vns->used, 32L * vns_launch_k + 1024);
             if (want > ctx->vns_rand_cap) {
                 if (ctx->d_vns_rand) hipFree(ctx->d_vns_rand);
@@ -4375,6 +4378,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 94: ctx->opt_vns_launch_k = value > 0 ? (int)std::min<long>(value, 65536) : 65536; break; // undocumented: VNS iterations per launch (tests)
     case 95: ctx->opt_lp_poll_sleep = (int)value; break; // undocumented: s_sleep(1) repetitions between polls of the exchange slots (tools/persist_probe.py)
     case 96: ctx->opt_lp_fail_at = (int)value; break; // undocumented: see opt_lp_fail_at (tests)
     case 97: ctx->opt_lp_hello = value ? value : 200000; ctx->lp_skip = 0; ctx->lp_backoff = 16; break; // undocumented: rendezvous limit of k_lds2opt (tests)
@@ -4428,6 +4432,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 20: return ctx->lp_used && ctx->lp_window ? 1 : 0;
     case 21: return ctx->lp_handed ? 1 : 0;
     case 22: return ctx->lp_sweeps;
+    case 23: return ctx->vns_mode;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
@@ -4844,15 +4849,18 @@ int tspgpu_vns_search(tspgpu_ctx *ctx, int *path, double *cost, int k, double ti
         bool ran = false;
         ctx->lp_handed = false;
         if ((rc = run_persist(ctx, 0, &left, &late, &ran, nullptr, &pv))) return rc;
-        if (ctx->lp_handed) return fail(ctx, E_INTERNAL, "LDS-resident VNS: the grid lost its co-residency half way");
         resident_done = ran;
         if (!ran && ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident VNS loop does not apply (uint16 cells, n in [64, ~5400], one idle chip)");
-        if (ran) HIP_TRY(hipMemcpyAsync(best_path, ctx->d_best_succ, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        // the incumbent as far as the resident launches got (all of the walk; or, when the grid lost its co-residency half
+        // way, up to the last launch that completed: the slot then holds that launch's tour and the loop below goes on from it)
+        HIP_TRY(hipMemcpyAsync(best_path, ctx->d_best_succ, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (!ran && (rc = store_path(ctx, 0, path, cost, nullptr))) return rc;
     }
+    ctx->vns_mode = resident_done ? 1 : pv.it > pv.it_entry ? 3 : 2;
     if (!resident_done) {
         // one local search per iteration on the device (whatever kernels the instance takes), kicks on the host
         std::vector<int> succ(path, path + n), tour(n), before(n);
-        long cur = 0;
+        long cur = pv.used;                        // (numbers the resident launches consumed before the grid was lost)
         while (pv.it < k) {
             if (t_end >= 0 && now_s() >= t_end) { late = true; break; }
             if (!pv.phase) {
