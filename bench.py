@@ -52,7 +52,7 @@ DATA = os.path.join(GOLDEN, "data")
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec); ~6.3 TB/s achievable
 LDS_PEAK_GBS = 256 * 256 * 2.4    # MI355X_MICROARCH.md LDS: ds_read_b128 256 B/clk/CU x 256 CUs x 2.4 GHz = 157 TB/s
-EXCHANGE_FLOOR_US = 2.74          # profiles/r02_slot_exchange_probe.txt: one 256-workgroup slot exchange on an idle chip
+EXCHANGE_FLOOR_US = 2.1           # profiles/r03_xcd_exchange_probe.txt: one flat 256-workgroup slot exchange on an idle chip (2.0-2.2 us)
 
 _POINTS = {}
 
@@ -346,7 +346,8 @@ def main():
             out.update({"bound": "latency", "achieved": us, "peak": EXCHANGE_FLOOR_US, "unit": "us per sweep (lower is better)",
                         "frac": EXCHANGE_FLOOR_US / us,
                         "exchange_floor_us": EXCHANGE_FLOOR_US,
-                        "exchange_floor_source": "profiles/r02_slot_exchange_probe.txt (256 workgroups, 16-byte records at 64-byte stride)",
+                        "exchange_floor_source": "profiles/r03_xcd_exchange_probe.txt (256 workgroups, 16-byte records at 64-byte stride, flat: 2.0-2.2 us; "
+                                                 "the two-level form through the XCDs' L2s measures the same)",
                         "phase_us": ph,
                         "frac_nominal_hbm": achieved / HBM_PEAK_GBS, "achieved_nominal_hbm_GBs": achieved, "hbm_peak_GBs": HBM_PEAK_GBS,
                         "unit_of_work": "sweep (launch duration / sweeps run by the launch)",
