@@ -3361,6 +3361,10 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
                 // a whole number of workgroups per CU (an uneven last round costs a full one), the
                 // most that keeps runs of >= 8 edges (each run fetches P+1 rows: extra row <= 12 %)
                 int k = std::max(1, G / ctx->cus);
+                // (at most two workgroups per CU: a third one -- 320 .. 448-thread workgroups of uint16 tours around n = 6000
+                // fit three -- costs more in row traffic (P + 1 rows per P edges) and skew than it hides: n=6144 30.3 us per
+                // sweep with G = 768, 23.2 with G = 512; tools/tune_mid.py)
+                k = std::min(k, 2);
                 while (k > 1 && (n + ctx->cus * k - 1) / (ctx->cus * k) < 8) k--;
                 if ((n + ctx->cus * k - 1) / (ctx->cus * k) >= 8) { P = (n + ctx->cus * k - 1) / (ctx->cus * k); G = (n + P - 1) / P; }
             }
