@@ -73,13 +73,10 @@ enum {
                                    where it applies -- falls back to one launch per sweep when the grid cannot be
                                    co-resident --, 2 or fail with code 8 */
     TSPGPU_OPT_PERSIST_EDGES = 17, /* tour edges per workgroup of that kernel (0 = auto: ceil(n / CUs); at most 16 with whole
-                                   rows, 48 with half-window rows) */
+                                   rows, 24 with half-window rows) */
     TSPGPU_OPT_BUILD_KERNEL = 19,  /* tspgpu_build_costs with uint16 cells: 0 (default) the upper triangle computed once, every
                                    64 x 64 tile stored twice (as it is and transposed through LDS), 1 every cell computed
                                    (what int32 / f64 cells always do) */
-    TSPGPU_OPT_PERSIST_XCD = 20,   /* 1: small instances inside ONE XCD (the half-window kernel on the 32 CUs of XCD 0, up to 48 tour
-                                   edges per workgroup, n <= 1536; the per-sweep exchange stays in that XCD's L2).  Same results;
-                                   measured slower than the chip-wide forms (profiles/r03_one_xcd.txt), hence off by default */
     TSPGPU_OPT_PERSIST_WINDOW = 18 /* rows of that kernel: 0 auto (whole rows where they fit the chip's LDS, else the half
                                    window of n/2 cells ahead of the workgroup's own edges), 1 half-window rows wherever they
                                    apply, 2 whole rows only */
@@ -99,8 +96,7 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * edges per workgroup and LDS bytes per workgroup of that kernel on this instance (0: it does not apply), 19 window cells per
  * row of its half-window form (0: whole rows), 20 the last single-tour descent ran in the half-window form, 21 the last
  * single-tour descent began LDS-resident and was finished one launch per sweep (the grid lost its co-residency), 22 sweeps run by the last
- * LDS-resident descent / tabu walk / VNS walk, 24 the last LDS-resident descent / walk ran inside one XCD
- * (TSPGPU_OPT_PERSIST_XCD), 23 how the last tspgpu_vns_search ran (1 resident throughout, 2 one device local
+ * LDS-resident descent / tabu walk / VNS walk, 23 how the last tspgpu_vns_search ran (1 resident throughout, 2 one device local
  * search per iteration with the kicks on the host, 3 resident launches first, then -- the grid lost its co-residency -- host kicks) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 

@@ -1237,15 +1237,6 @@ def window(eng, T):
     eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_EDGES, 0); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
 
 
-@pytest.fixture
-def one_xcd(eng, T):
-    """TSPGPU_OPT_PERSIST_XCD = 1: k_lds2opt_w on the workgroups of XCD 0 alone (at most 32, up to 48 edges each), the
-    per-sweep exchange through that XCD's L2"""
-    eng.set_option(T.OPT_PERSIST, 2); eng.set_option(T.OPT_PERSIST_XCD, 1)
-    yield
-    eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_EDGES, 0); eng.set_option(T.OPT_PERSIST_XCD, 0)
-
-
 def _descent_against_oracle(eng, O, c, succ0, cost0, sweeps_cap):
     """one launch of at most sweeps_cap sweeps against as many ref_2opt_once calls of the oracle, move by move"""
     eng.set_option(5, 8192)                          # TSPGPU_OPT_HISTORY
@@ -1280,50 +1271,6 @@ def test_lds_window_to_local_optimum_golden(eng, T, O, instances, golden, name, 
     assert eng.info()["persist"] == 1 and eng.info()["persist_window"] == 1
     got, gcost, _ = eng.tour_store(0)
     assert (sw, gcost, fx(O, got)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
-
-
-@pytest.mark.parametrize("edges", [0, 40, 48])
-@pytest.mark.parametrize("name", ["kroA100", "n200_s3", "pr1002", "n1000_s123", "n1024_s1"])
-def test_one_xcd_to_local_optimum_golden(eng, T, O, instances, golden, name, edges, one_xcd):
-    """the same descents inside ONE XCD: golden sweep count, final cost, tour and every recorded move"""
-    xy, c = setup(eng, T, O, instances, name, 3, 0)
-    eng.set_option(T.OPT_PERSIST_EDGES, edges)
-    if eng.info()["persist_window_cells"] == 0:
-        pytest.skip("the window of this many edges does not fit n")
-    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
-    succ, nn_cost = O.nn_tour(c, 0)
-    sw = _descent_against_oracle(eng, O, c, succ, nn_cost, -1)
-    info = eng.info()
-    assert info["persist"] == 1 and info["persist_window"] == 1 and info["persist_xcd"] == 1 and info["persist_wgs"] <= 32
-    got, gcost, _ = eng.tour_store(0)
-    assert (sw, gcost, fx(O, got)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
-
-
-@pytest.mark.parametrize("n", [64, 97, 513, 1000, 1279, 1536])
-def test_one_xcd_size_sweep(eng, T, O, n, one_xcd):
-    """sizes up to the one-XCD limit (32 workgroups x 48 edges): 40 sweeps in one launch against the oracle, move by move"""
-    xy = O.random_points(n, 4000 + n)
-    c = O.cost_matrix(xy)
-    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
-    eng.set_points(xy); eng.build_costs()
-    succ, cost = O.nn_tour(c, n // 3)
-    _descent_against_oracle(eng, O, c, succ, cost, 40)
-    assert eng.info()["persist"] == 1 and eng.info()["persist_xcd"] == 1
-
-
-def test_one_xcd_is_opt_in_and_ends_at_its_limit(eng, T, O):
-    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_PERSIST, 1)
-    try:
-        for n, opt, want in ((1200, 0, 0), (1200, 1, 1), (1537, 1, 0), (2000, 1, 0)):
-            eng.set_option(T.OPT_PERSIST_XCD, opt)
-            xy = O.random_points(n, 5000 + n)
-            c = O.cost_matrix(xy)
-            eng.set_points(xy); eng.build_costs()
-            succ, cost = O.nn_tour(c, 1)
-            _descent_against_oracle(eng, O, c, succ, cost, 10)
-            assert eng.info()["persist"] == 1 and eng.info()["persist_xcd"] == want, (n, opt)
-    finally:
-        eng.set_option(T.OPT_PERSIST_XCD, 0)
 
 
 def test_lds_window_fnl4461_config3(eng, T, O, golden):
@@ -1446,7 +1393,7 @@ def _oracle_vns(O, c, succ0, cost0, k, seed, rv):
     return best, bc, s, used
 
 
-@pytest.mark.parametrize("mode", ["resident", "window", "one_xcd", "host_kicks"])
+@pytest.mark.parametrize("mode", ["resident", "window", "host_kicks"])
 @pytest.mark.parametrize("name,k", [("kroA100", 200), ("n200_s3", 150), ("pr1002", 40), ("n1000_s123", 40)])
 def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
     """mh_VNS (metaheuristic.c:279-318): k iterations of local search + kicks in ONE launch (LDS-resident kernels: whole rows
@@ -1456,7 +1403,6 @@ def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
     xy, c = setup(eng, T, O, instances, name, 3, 0)
     eng.set_option(T.OPT_PERSIST, 0 if mode == "host_kicks" else 2)
     eng.set_option(T.OPT_PERSIST_WINDOW, 1 if mode == "window" else 0)
-    eng.set_option(T.OPT_PERSIST_XCD, 1 if mode == "one_xcd" else 0)
     try:
         seed0, cost0 = O.nn_tour(c, 7)
         rv = _libc_draws(O, 5, 64 * k + 4096)
@@ -1464,8 +1410,7 @@ def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
         path, best = seed0.copy(), seed0.copy()
         r = eng.vns_search(path, k, rv, best, cost0, want_trace=True)
         info = eng.info()
-        assert info["persist"] == (0 if mode == "host_kicks" else 1) and info["persist_window"] == (1 if mode in ("window", "one_xcd") else 0)
-        assert info["persist_xcd"] == (1 if mode == "one_xcd" else 0)
+        assert info["persist"] == (0 if mode == "host_kicks" else 1) and info["persist_window"] == (1 if mode == "window" else 0)
         assert (r["rc"], r["iterations"], r["kick_pending"]) == (0, k, 0)
         assert r["best_cost"] == obc and np.array_equal(best, obest)
         assert np.array_equal(path, ofinal) and r["consumed"] == oused
@@ -1473,7 +1418,7 @@ def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
         tr = r["trace"]
         assert len(tr) == k and tr.min() == obc and not np.isnan(tr).any()
     finally:
-        eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_WINDOW, 0); eng.set_option(T.OPT_PERSIST_XCD, 0)
+        eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
 
 
 @pytest.mark.parametrize("mode", ["resident", "host_kicks"])
@@ -1576,27 +1521,6 @@ def test_lds_window_tabu_walk(eng, T, O, instances, name, k, edges, window):
     assert final == ofinal and np.array_equal(seed, oseed)
     assert best_cost == obc and np.array_equal(best, obest)
     assert O.valid_tour(best) and O.tour_cost(c, best) == best_cost
-
-
-@pytest.mark.parametrize("edges", [0, 48])
-@pytest.mark.parametrize("name,k", [("kroA100", 400), ("n200_s3", 400), ("pr1002", 200), ("n1024_s1", 150)])
-def test_one_xcd_tabu_walk(eng, T, O, instances, name, k, edges, one_xcd):
-    """the tabu walk inside ONE XCD: every iteration's cost, the final tour, the best tour and its cost"""
-    xy, c = setup(eng, T, O, instances, name, 3, 0)
-    eng.set_option(T.OPT_PERSIST_EDGES, edges)
-    if eng.info()["persist_window_cells"] == 0:
-        pytest.skip("the window of this many edges does not fit n")
-    seed, cost = O.nn_tour(c, 0)
-    if name != "n1024_s1":                               # (n1024: from the raw NN tour -- long reversals first, then uphill)
-        O.two_opt(c, seed)
-        cost = O.tour_cost(c, seed)
-    oseed = seed.copy()
-    best, best_cost, final, trace = eng.tabu_search(seed, cost, k, want_trace=True)
-    assert eng.info()["persist"] == 1 and eng.info()["persist_xcd"] == 1
-    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
-    bad = np.nonzero(trace != otrace)[0]
-    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
-    assert final == ofinal and np.array_equal(seed, oseed) and best_cost == obc and np.array_equal(best, obest)
 
 
 def test_lds_window_tabu_from_nn_and_ties(eng, T, O, instances, window):

@@ -7,15 +7,15 @@ the cells k+1 .. k + n/2 + 1 inside its evaluated chunks.  A slip here would sho
 import numpy as np
 import pytest
 
-CUS, LW_EMAX, LW_BT, LW_FIX, LDS_MAX = 256, 48, 768, 128, 160 * 1024
+CUS, LW_EMAX, LW_BT, LW_FIX, LDS_MAX = 256, 24, 768, 128, 160 * 1024
 POISON = 65535
 
 
-def geometry(n, edges=0, wgs=CUS):
-    """persist_fits_w of csrc/tspgpu.hip (wgs = 32: the one-XCD form)"""
+def geometry(n, edges=0):
+    """persist_fits_w of csrc/tspgpu.hip"""
     if n < 64 or n > 8191:
         return None
-    e = max(-(-n // wgs), edges)
+    e = max(-(-n // CUS), edges)
     if e > LW_EMAX:
         return None
     ws = (e + n // 2 + 23) & ~7
@@ -27,7 +27,7 @@ def geometry(n, edges=0, wgs=CUS):
     if fixed + ns * nl * 2 > LDS_MAX:
         return None
     W = -(-n // e)
-    if W > wgs:
+    if W > CUS:
         return None
     return dict(E=e, W=W, Ws=ws, nstage=ns, lds=fixed + ns * nl * 2)
 
@@ -37,15 +37,11 @@ def test_limits():
     assert geometry(5376) is not None and geometry(5400) is not None
     assert geometry(5800) is None
     assert geometry(64) is not None and geometry(63) is None
-    # inside one XCD (32 workgroups): up to 48 edges each
-    assert geometry(1024, wgs=32)["E"] == 32 and geometry(1536, wgs=32)["E"] == 48 and geometry(1537, wgs=32) is None
-    assert geometry(1002, wgs=32)["W"] == 32 and geometry(64, wgs=32)["E"] == 2
 
 
-@pytest.mark.parametrize("n,edges,wgs", [(64, 0, 256), (97, 0, 256), (200, 3, 256), (513, 0, 256), (1000, 16, 256), (1002, 24, 256),
-                                         (4461, 0, 256), (5399, 0, 256), (97, 0, 32), (1002, 0, 32), (1024, 0, 32), (1536, 0, 32), (1400, 48, 32)])
-def test_every_pair_has_an_owner(n, edges, wgs):
-    g = geometry(n, edges, wgs)
+@pytest.mark.parametrize("n,edges", [(64, 0), (97, 0), (200, 3), (513, 0), (1000, 16), (1002, 24), (4461, 0), (5399, 0)])
+def test_every_pair_has_an_owner(n, edges):
+    g = geometry(n, edges)
     assert g is not None
     E, W, Ws = g["E"], g["W"], g["Ws"]
     NC = (Ws >> 3) - 1
@@ -156,10 +152,9 @@ class WG:
                 self.reloads += 1
 
 
-@pytest.mark.parametrize("n,edges,seed,wgs", [(64, 0, 1, 256), (97, 0, 2, 256), (200, 3, 3, 256), (333, 16, 4, 256), (1000, 24, 5, 256), (513, 0, 6, 256),
-                                              (3000, 0, 7, 256), (1002, 0, 8, 32), (1536, 0, 9, 32), (700, 40, 10, 32)])
-def test_window_rows_follow_the_moves(n, edges, seed, wgs):
-    g = geometry(n, edges, wgs)
+@pytest.mark.parametrize("n,edges,seed", [(64, 0, 1), (97, 0, 2), (200, 3, 3), (333, 16, 4), (1000, 24, 5), (513, 0, 6), (3000, 0, 7)])
+def test_window_rows_follow_the_moves(n, edges, seed):
+    g = geometry(n, edges)
     assert g is not None
     E, W, Ws = g["E"], g["W"], g["Ws"]
     rs = np.random.RandomState(seed)

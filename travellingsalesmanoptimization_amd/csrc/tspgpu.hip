@@ -2948,9 +2948,6 @@ struct tspgpu_ctx {
     // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
     int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
-    int opt_persist_xcd = 0;    // 1: inside ONE XCD wherever its 32 CUs hold the half windows
-    int lp_xcd_off = 0;         // descents for which the one-XCD form is skipped (XCD 0 did not get its workgroups)
-    bool lp_xcd = false;        // the last LDS-resident descent ran inside one XCD
     int opt_build = 0;          // K1 for integer cells: 0 one triangle + transposed store (k_build_costs_tri), 1 every cell computed (k_build_costs_int)
     int opt_persist_window = 0; // 0 auto (half-window rows where whole rows do not fit the chip's LDS), 1 always, 2 never
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
@@ -3709,14 +3706,11 @@ static bool persist_fits(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, boo
 
 // The half-window form (k_lds2opt_w): every row kept as the window of E + n/2 + 16.. cells ahead of the workgroup's first own
 // cell, so that instances a little past n = 4096 (fnl4461, BASELINE config 3) stay LDS-resident.  Plain 2-opt only.
-// wgs_max: the workgroups the descent may spread over -- a whole chip's (256), or the 32 of ONE XCD (small n: the exchange then
-// stays inside that XCD's L2)
-static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, int &Ws, int &nstage, bool tabu = false, int wgs_max = 256)
+static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, int &Ws, int &nstage, bool tabu = false)
 {
     const int n = ctx->n;
     if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 64 || n > 8191) return false;
-    const int wm = std::min(ctx->cus, wgs_max);
-    int e = (n + wm - 1) / wm;
+    int e = (n + std::min(ctx->cus, 256) - 1) / std::min(ctx->cus, 256);
     if (ctx->opt_persist_edges > e) e = ctx->opt_persist_edges;
     if (e > LW_EMAX) return false;
     const int ws = (e + n / 2 + 23) & ~7;             // window cells per row (see k_lds2opt_w)
@@ -3728,7 +3722,7 @@ static bool persist_fits_w(const tspgpu_ctx *ctx, int &E, int &W, size_t &lds, i
     if (fixed + 2 * nl * 2 > ctx->lds_max) ns = 1;
     if (fixed + (size_t)ns * nl * 2 > ctx->lds_max) return false;
     E = e; W = (n + e - 1) / e; Ws = ws; nstage = ns; lds = fixed + (size_t)ns * nl * 2;
-    return W <= wm;
+    return W <= ctx->cus && W <= 256;
 }
 
 // *ran = false: nothing was touched (does not apply, or the grid did not come up co-resident): the caller takes the
@@ -3758,20 +3752,15 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     const double time_left_s = time_left_io ? *time_left_io : -1.0;
     int E = 0, W = 0, Ws = 0, nstage = 0;
     size_t lds = 0;
-    bool win = false, xcd = false;
-    // small instances: inside ONE XCD (half-window kernel, exchange through that XCD's L2) where its 32 CUs hold the windows
-    // (opt-in: measured slower than the chip-wide forms at every n it holds -- profiles/r03_one_xcd.txt)
-    if (ctx->opt_persist_xcd == 1 && ctx->lp_xcd_off <= 0 && ctx->cus >= 256 && ctx->opt_persist_window != 2 &&
-        persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr, 32)) win = xcd = true;
-    else if (ctx->opt_persist_window == 1 && persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr)) win = true;
+    bool win = false;
+    if (ctx->opt_persist_window == 1 && persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr)) win = true;
     else if (!persist_fits(ctx, E, W, lds, tabu != nullptr)) {
         if (ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, nstage, tabu != nullptr)) return E_OK;
         win = true;
     }
-    if (ctx->lp_xcd_off > 0) ctx->lp_xcd_off--;
     if (ctx->lp_skip > 0) { ctx->lp_skip--; return E_OK; }
     if (!ctx->d_lp_slots) {
-        HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 128));     // exchange slots, then the control words, then the XCD counter
+        HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));      // exchange slots, then the control words
         HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
     }
     if ((tabu || vns) && ctx->lp_best_n < ctx->ld) {
@@ -3815,7 +3804,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             budget = (int)std::min(1048576.0, std::max(1.0, left / 3.0 / sweep_s));
         }
         int *d_ctl = reinterpret_cast<int *>(ctx->d_lp_slots + (size_t)2 * W * 8);   // (one memset for both)
-        HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64 + 128, ctx->stream));
+        HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64 + 64, ctx->stream));
         if (tabu || vns) HIP_TRY(hipMemsetAsync(ctx->d_lp_best + ctx->ld, 0, 8, ctx->stream));
         int vns_launch_k = 0;
         if (vns) {
@@ -3848,7 +3837,6 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         if (ctx->opt_lp_fail_at > 0 && !first) { ctx->opt_lp_fail_at--; A.hello_ticks = -5000; }   // test hook 96: the next N relaunches fail their rendezvous
         A.spin_ticks = 100000000;      // 1 s
         A.poll_sleep = ctx->opt_lp_poll_sleep;
-        A.xcd = xcd ? 1 : 0; A.W_eff = W; A.xcd_meta = d_ctl + 16;
         A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
         if (tabu) {
             A.budget = -1;
@@ -3870,8 +3858,7 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
         }
         {
-            // (one XCD: a whole chip's worth of workgroups, one per CU -- the LDS request sees to that --, of which XCD 0's work)
-            const hipError_t le = hipLaunchKernel(fn, dim3(xcd ? ctx->cus : W), dim3(block), args, xcd ? std::max<size_t>(lds, 84 * 1024) : lds, ctx->stream);
+            const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(block), args, lds, ctx->stream);
             if (le != hipSuccess) {                    // (e.g. a device that does not grant 160 KiB of LDS to one workgroup)
                 (void)hipGetLastError();
                 if (first) { ctx->lp_skip = 1 << 30; return E_OK; }      // (this device never grants the launch)
@@ -3888,11 +3875,6 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         if (vns) HIP_TRY(hipMemcpyAsync(ctx->h_lp + 8, reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost), 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
-        if (xcd && first && (status == LP_ST_NO_RENDEZVOUS || status == LP_ST_RUNNING)) {
-            // XCD 0 did not get its workgroups (placement is the hardware's business): the chip-wide form, now and for a while
-            ctx->lp_xcd_off = 64;
-            return run_persist(ctx, slot, time_left_io, deadline_hit, ran, tabu, vns);
-        }
         if (status == LP_ST_NO_RENDEZVOUS) {
             if (first) {                                               // nothing written: the other path takes over
                 ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
@@ -3942,7 +3924,6 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     *ran = true;
     ctx->lp_used = true;
     ctx->lp_window = win;
-    ctx->lp_xcd = xcd;
     return E_OK;
 }
 
@@ -4415,7 +4396,6 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
     case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LW_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LW_EMAX); ctx->opt_persist_edges = (int)value; break;
-    case TSPGPU_OPT_PERSIST_XCD: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad one-XCD mode"); ctx->opt_persist_xcd = (int)value; ctx->lp_xcd_off = 0; break;
     case TSPGPU_OPT_BUILD_KERNEL: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad build kernel"); ctx->opt_build = (int)value; break;
     case TSPGPU_OPT_PERSIST_WINDOW: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad window mode"); ctx->opt_persist_window = (int)value; break;
     case TSPGPU_OPT_PIPE2: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad pipe2 mode"); ctx->opt_pipe2 = (int)value; ctx->plan_kernel = 0; drop_graphs(ctx); break;
@@ -4446,8 +4426,6 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 15: return ctx->lp_used ? 1 : 0;
     case 16: case 17: case 18: case 19: {    // geometry of the LDS-resident descent (0: it does not apply to the instance)
         int E = 0, W = 0, Ws = 0, ns = 0; size_t lds = 0;
-        if (ctx->opt_persist_xcd == 1 && ctx->cus >= 256 && ctx->opt_persist_window != 2 && persist_fits_w(ctx, E, W, lds, Ws, ns, false, 32))
-            return what == 16 ? W : what == 17 ? E : what == 18 ? (long)lds : Ws;
         const bool full = ctx->opt_persist_window != 1 && persist_fits(ctx, E, W, lds);
         if (!full && (ctx->opt_persist_window == 2 || !persist_fits_w(ctx, E, W, lds, Ws, ns))) {
             if (!persist_fits(ctx, E, W, lds)) return 0;
@@ -4459,7 +4437,6 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 21: return ctx->lp_handed ? 1 : 0;
     case 22: return ctx->lp_sweeps;
     case 23: return ctx->vns_mode;
-    case 24: return ctx->lp_used && ctx->lp_xcd ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }
