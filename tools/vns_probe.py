@@ -37,4 +37,22 @@ for name, xy in (("pr1002", read_tsplib(os.path.join(ROOT, "tests", "golden", "d
         extra = f", {sw} sweeps = {sw/kk:.1f} per iteration, {min(ts)/max(sw,1)*1e6:.2f} us per sweep all in" if sw else ""
         print(f"{name} persist={mode} used={i['persist']} window={i['persist_window']}: {kk} iterations in {min(ts)*1e3:.2f} ms = {min(ts)/kk*1e6:.1f} us per iteration, "
               f"best {r['best_cost']:.0f} (start {c0:.0f}), {r['consumed']} numbers consumed ({r['consumed']/kk:.1f} per iteration), rc={r['rc']}{extra}", flush=True)
+    # phase clocks of one launch (option 98): the kick phase of an iteration in parts, and the sweeps by phase
+    eng.set_option(T.OPT_PERSIST, 1)
+    if name != "fnl4461":                                  # (the whole-row kernel keeps these clocks)
+        eng.set_option(98, 1)
+        path, best = seed.copy(), seed.copy()
+        kk = min(k, 1000)
+        r = eng.vns_search(path, kk, rv, best, c0)
+        buf = np.zeros(1024 * 64, dtype=np.uint64)
+        eng.L.tspgpu_debug_stamps(eng.ctx, buf.ctypes.data, buf.size)
+        eng.set_option(98, 0)
+        st = buf.reshape(-1, 16)[:256].astype(np.float64)
+        st = st[st[:, 8] > 0]
+        it = r["iterations"]
+        names = ["evaluation", "reduction", "exchange", "reversal", "rows fetched", "decode+swaps"]
+        print(f"  {name}: {len(st)} workgroups, {int(st[0, 8])} sweeps, {it} iterations; us per ITERATION, mean over workgroups: " +
+              ", ".join(f"{nm} {(st[:, i2] / it / 100.0).mean():.1f}" for i2, nm in enumerate(names)) +
+              f" | kicks {(st[:, 13] / it / 100.0).mean():.2f}, edge costs + sum {(st[:, 14] / it / 100.0).mean():.2f}, all rows again {(st[:, 15] / it / 100.0).mean():.2f}"
+              f" | rows fetched per workgroup and iteration {st[:, 7].mean() / it:.1f} in {st[:, 6].mean() / it:.2f} fetches", flush=True)
     eng.close()
