@@ -29,7 +29,7 @@ Objects on the same JSON line (rank 0; the auxiliary legs run after the timed re
                          against a committed golden, its roofline and a bounded CPU sample)
   multistart_batch       64 starts in flight (NN + 2-opt, the throughput-bound regime)
   otf                    matrix-free sweep on pla85900 (config 5): bound "valu", ceiling from the kernel's ISA
-                         (tools/otf_isa_count.py -> profiles/r02_otf_isa_ceiling.json)
+                         (tools/otf_isa_count.py -> profiles/r03_otf_isa_ceiling.json)
   cpu_multistart_baseline  All-NN+2OPT on pr1002, all 1002 starts: the reference on ALL host cores of this box's share
                          (one process per core over disjoint start ranges) next to the engine's time
   host_c_path            the drop-in `tsp` binary (C host layer, TSP_GPU_DEVICES = the N devices of this run): the
@@ -574,7 +574,7 @@ def main():
                 e3.close()
             m = len(pts)
             ev = T.evals_per_sweep(m)
-            ceil = json.load(open(os.path.join(ROOT, "profiles", "r02_otf_isa_ceiling.json")))["3"]   # CEIL_2D, integer coordinates
+            ceil = json.load(open(os.path.join(ROOT, "profiles", "r03_otf_isa_ceiling.json")))["3"]   # CEIL_2D, integer coordinates
             return {"workload": f"pla85900 ({ewt}, n={m}), matrix-free: no n x n array (59 GB of doubles in the reference's format)",
                     "matrix_free": info["matrix_free"], "ms_per_sweep": ms, "evals_per_sweep": ev, "value": ev / (ms * 1e-3),
                     "unit": "evals/s", "nn_tour_s": nn_s, "nn_cost": c_nn,
@@ -582,8 +582,8 @@ def main():
                                  "frac": ev / (ms * 1e-3) / ceil["ceiling_evals_per_s"], "traffic": None,
                                  "kernel": ceil["kernel"], "issue_cycles_per_pair": ceil["issue_cycles_per_pair"],
                                  "valu_per_pair": ceil["valu_per_pair"], "clock_hz": ceil["clock_hz"],
-                                 "derivation": "static VALU count of the kernel's ISA priced per instruction class: "
-                                               "tools/otf_isa_count.py -> profiles/r02_otf_isa_ceiling.json (lower bound of the ceiling)"}}
+                                 "derivation": "static VALU count of the kernel's step loop (8 pair evaluations) priced per instruction class: "
+                                               "tools/otf_isa_count.py -> profiles/r03_otf_isa_ceiling.json "}}
         otf = guarded(otf_leg)
 
     # ---- All-NN+2OPT over all 1002 starts of pr1002: the engine vs the reference on every host core of this box's share

@@ -80,6 +80,49 @@ def test_matrix_att_ceil(eng, T, O):
         assert np.array_equal(eng.build_costs(fetch=True), O.cost_matrix(xy, kind))
 
 
+def test_ceil_2d_integer_weights_exact(eng, T, O):
+    """CEIL_2D on integer coordinates (edge_w<KIND_CEIL_INT>: f32 root + one exact remainder): every cell equals the exact
+    integer ceil-sqrt -- which is what the double arithmetic of the TSPLIB definition gives below 2^44 -- on points
+    built to hit the decision's edges: perfect squares, perfect squares +- 1, Pythagorean multiples, weights just below
+    2^22 (the largest the kind is used for); past that bound the generic double arithmetic takes over and must agree too"""
+    import math
+    r = np.random.RandomState(5)
+    pts = [(0, 0), (1, 0), (0, 1), (1, 1), (2, 1), (3, 4), (2900000, 0), (2900000, 1), (0, 2900000), (2050000, 2050000),
+           (2050001, 2050000), (1448153, 1448155), (4095, 4095), (4096, 0), (4097, 1), (1234567, 2345678)]
+    pts += [(3 * k, 4 * k) for k in (7, 1000, 99991, 500000)] + [(5 * k, 12 * k) for k in (3, 77777, 200000)]
+    pts += [(k * k % 2900001, (k * 7919) % 2900001) for k in range(1, 200)]
+    pts += [tuple(int(v) for v in r.randint(0, 2900000, size=2)) for _ in range(300)]
+    pts += [(int(x), 0) for x in r.randint(1, 2000, size=60) ** 2] + [(int(x) + 1, 0) for x in r.randint(1, 1700, size=60) ** 2]
+    xy = np.array(sorted(set(pts)), dtype=np.float64)
+    n = len(xy)
+    want = np.empty((n, n), dtype=np.float64)
+    for i in range(n):
+        for j in range(n):
+            d2 = int(xy[i, 0] - xy[j, 0]) ** 2 + int(xy[i, 1] - xy[j, 1]) ** 2
+            k = math.isqrt(d2)
+            want[i, j] = -1.0 if i == j else float(k if k * k == d2 else k + 1)
+    assert np.array_equal(want, O.cost_matrix(xy, O.CEIL_2D))                 # (the oracle's doubles agree: d2 < 2^44)
+    for elem in (0, 1, 2):
+        eng.set_option(T.OPT_ELEM, elem)
+        eng.set_points(xy, T.CEIL_2D)
+        assert np.array_equal(eng.build_costs(fetch=True), want), elem
+    # the same weights through the matrix-free sweep and the NN grid kernel: NN tour cost and the first 2-opt moves
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_MATRIX_FREE, 1)
+    try:
+        eng.set_points(xy, T.CEIL_2D); eng.build_costs()
+        succ, cost = eng.nn_tour(0)
+        osucc, ocost = O.nn_tour(want, 0)
+        assert cost == ocost and np.array_equal(succ, osucc)
+        cost2, sweeps, rc = eng.two_opt(succ)
+        osw, ocost2 = O.two_opt(want, osucc)
+        assert (cost2, sweeps) == (ocost2, osw) and np.array_equal(succ, osucc)
+    finally:
+        eng.set_option(T.OPT_MATRIX_FREE, 0)
+    big = xy * 8.0                                                            # weights up to 3.3e7: past the kind's bound
+    eng.set_points(big, T.CEIL_2D)
+    assert np.array_equal(eng.build_costs(fetch=True), O.cost_matrix(big, O.CEIL_2D))
+
+
 def test_set_costs_roundtrip_and_kind(eng, T, O, instances):
     _, c = instances("kroA100")
     eng.set_option(T.OPT_ELEM, 0)

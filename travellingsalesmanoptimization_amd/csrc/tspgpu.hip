@@ -240,9 +240,16 @@ __device__ __forceinline__ typename Elem<T>::acc cell(const T *mat, const double
 // One integer edge weight, specialised on the kind (no branch in the inner loop).  EUC_2D: the
 // correctly rounded f32 root written out exactly as hipcc expands sqrtf() -- v_sqrt_f32 (1 ulp)
 // and one fix-up step on either side with two FMAs -- minus the denormal scaling and the class
-// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates: d2 is an
-// exact integer below 2^52, so ceil(sqrt(d2)) is the smallest k with k*k >= d2; k starts from
-// the f32 root (within 1 of the floor) and is corrected with exact f64 products.
+// test that weights (0 or >= 1) cannot need.  KIND 3 = CEIL_2D on integer coordinates with every
+// weight below 2^22 (ceil_int()): d2 is an exact integer below 2^44, so ceil(sqrt(d2)) is the
+// smallest j with j*j >= d2.  The f32 root r is within 0.375 of sqrt(d2) (the conversion of d2
+// costs the root 2^-25 relative, v_sqrt_f32 one ulp <= 0.25), so k = floor(r) is
+// floor(sqrt(d2)) - 1, + 0 or + 1, and ONE exact remainder e = d2 - k*k (an integer of at most 24
+// bits) decides between k - 1 .. k + 2 in 32-bit integer arithmetic:
+//     e > 0:  (k+1)^2 >= d2  <=>  e <= 2k + 1  ->  k + 1, else k + 2
+//     e = 0:  k
+//     e < 0:  (k-1)^2 >= d2  <=>  e + 2k - 1 <= 0  ->  k - 1, else k
+// (round 2's form corrected k three times in a row with f64 products: 14 f64 instructions per weight in a dependent chain.)
 constexpr int KIND_CEIL_INT = 3;
 // F32R (EUC_2D only): the final (int)((double)root + 0.5) in f32 -- exact while the root is below 2^22 (root + 0.5f is then
 // representable: 0.5 is a multiple of the root's ulp), three f64 conversions / additions less per weight
@@ -250,7 +257,9 @@ template <int KIND, bool F32R = false>
 __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by)
 {
     const double dx = bx - ax, dy = by - ay;
-    const double sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
+    double sq;
+    if constexpr (KIND == KIND_CEIL_INT) sq = __builtin_fma(dy, dy, dx * dx);   // (integers: every step exact, fused or not)
+    else sq = dx * dx + dy * dy; // -ffp-contract=off: no fma
     if constexpr (KIND == TSPGPU_EUC_2D) {
         const float x = (float)sq;
         const float r = __builtin_amdgcn_sqrtf(x);
@@ -261,11 +270,11 @@ __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by
         if constexpr (F32R) return (int)(c + 0.5f);
         return (int)((double)c + 0.5);
     } else if constexpr (KIND == KIND_CEIL_INT) {
-        double k = (double)(int)__builtin_amdgcn_sqrtf((float)sq);
-        k = k * k < sq ? k + 1.0 : k;
-        k = k * k < sq ? k + 1.0 : k;
-        k = (k > 0.0 && (k - 1.0) * (k - 1.0) >= sq) ? k - 1.0 : k;
-        return (int)k;
+        const int ki = (int)__builtin_amdgcn_sqrtf((float)sq);
+        const double k = (double)ki;
+        const int e = (int)__builtin_fma(-k, k, sq), t1 = 2 * ki + 1;
+        const int up = e > t1 ? 2 : 1, down = e + t1 <= 2 ? -1 : 0;
+        return ki + (e > 0 ? up : e < 0 ? down : 0);
     } else return (int)edge_weight(ax, ay, bx, by, KIND);
 }
 
@@ -2449,10 +2458,11 @@ __global__ void __launch_bounds__(256) k_gather_spts(Tours S, int n, int slot0, 
 // per pair ONE 32-bit min on (w1 + w2 - c[b][sb]) << 2 | v keeps the reference's tie order.
 // Per pair that leaves the two weights and three integer instructions.
 // ---------------------------------------------------------------------------
+constexpr int OTF8_RUN = 16;        // tour edges per workgroup: the per-b arrays (36 bytes per b) are streamed once per RUN pairs
 template <int KIND, bool TABU>
 __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
 {
-    constexpr int RUN = 8, VB = 4, VSH = 2;     // 4 b's per thread: 8 need > 128 registers (two waves per SIMD only)
+    constexpr int RUN = OTF8_RUN, VB = 4, VSH = 2;     // 4 b's per thread: 8 need > 128 registers (two waves per SIMD only)
     __shared__ int nodes_s[RUN + 2];
     __shared__ double2 npt[RUN + 1];
     __shared__ int dstep[RUN];
@@ -2915,6 +2925,7 @@ struct tspgpu_ctx {
     int opt_nn = 0;          // 0 auto, 1 matrix / strided kernels, 2 grid kernel
     double cost_bound = 0;   // upper bound of any entry the uploaded points can produce
     bool int_coords = false; // every coordinate an integer below 2^25 in magnitude
+    bool ceil_int() const { return kind == TSPGPU_CEIL_2D && int_coords && cost_bound < 4194304.0; }   // edge_w<KIND_CEIL_INT> applies
     int *d_flags = nullptr;
 
     // tours
@@ -3299,7 +3310,8 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             HIP_TRY(hipMalloc(&ctx->d_spts, (size_t)ntours * n * sizeof(double2)));
             ctx->spts_cap = (size_t)ntours * n;
         }
-        P = 8; G = (n + P - 1) / P;
+        P = (ctx->cost_bound < 33554432.0 && n < 131072) ? OTF8_RUN : 8;     // (k_sweep_otf8 / k_sweep_otf: see launch_sweep)
+        G = (n + P - 1) / P;
         if (G > ctx->S.pstride) return fail(ctx, E_INTERNAL, "partial stride %d < %d workgroups", ctx->S.pstride, G);
         ctx->plan_kernel = 4; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = 256; ctx->plan_NCH = 0; ctx->plan_D = 0;
         ctx->plan_T = ntours; ctx->plan_lds = 0;
@@ -3427,7 +3439,7 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
         HIP_TRY(hipGetLastError());
         const void *fo = tabu ? (const void *)k_sweep_otf<true> : (const void *)k_sweep_otf<false>;
         if (ctx->cost_bound < 33554432.0 && n < 131072) {     // 2^25, 17-bit labels
-            const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+            const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
 #define OTF8(K) (tabu ? (const void *)k_sweep_otf8<K, true> : (const void *)k_sweep_otf8<K, false>)
             fo = kind == TSPGPU_EUC_2D ? OTF8(TSPGPU_EUC_2D) : kind == TSPGPU_ATT ? OTF8(TSPGPU_ATT)
                : kind == KIND_CEIL_INT ? OTF8(KIND_CEIL_INT) : OTF8(TSPGPU_CEIL_2D);
@@ -4235,7 +4247,7 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
         const bool lp = count <= ctx->cus && lds + (size_t)n * 24 + 64 <= ctx->lds_max;
         if (lp) lds += (size_t)n * 24;
         const bool key32 = ctx->cost_bound < 32767.0 && n <= 131072;      // (weight << 17 | node) in one 32-bit word, below the "none" key
-        const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+        const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
         // ... and, where they fit beside them, the 3 nearest neighbours of every point (built once per instance)
         // (in LDS for a single tour; batches and tours whose points do not fit LDS read them from global memory)
         const int knn = !key32 || ctx->opt_nn == 3 ? 0 : (lp && lc && lds + (size_t)n * NN_K * 4 <= ctx->lds_max) ? 1 : !lp ? 2 : 0;
@@ -4475,7 +4487,7 @@ static int launch_build(tspgpu_ctx *ctx)
         dim3 grid((ld / 2 + 255) / 256, n);
         hipLaunchKernelGGL((k_build_costs<double>), grid, dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, ctx->kind, (double *)ctx->d_mat);
     } else {
-        const int kind = (ctx->kind == TSPGPU_CEIL_2D && ctx->int_coords) ? KIND_CEIL_INT : ctx->kind;
+        const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
         // one triangle + transposed store (k_build_costs_tri); TSPGPU_OPT_BUILD_KERNEL = 1 keeps the full-matrix form
         const int NT = (n + TRI - 1) / TRI;
         // (uint16 cells only: with int32 cells the 64-byte row segments of the transposed tiles store slower than the
