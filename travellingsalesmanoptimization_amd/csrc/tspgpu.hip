@@ -3328,6 +3328,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         return (int)std::min<long>(8, fit);
     };
     const bool res_ok = res_nch <= (ctx->elem == TSPGPU_ELEM_U16 ? 1 : 2) && res_P() >= 2 && n >= 8;
+    const bool batch_streams = ntours > 1 && n >= 256 && (size_t)n * row <= ((size_t)256 << 20) && ctx->opt_wgs <= 0;
     if (kernel == 3 && !res_ok) return fail(ctx, E_EXHAUSTED, "resident sweep: rows of %zu B do not fit", row);
     if (kernel == 0) {
         // uint16: resident whenever it fits.  int32 / f64: resident only while 9 rows leave room
@@ -3335,7 +3336,13 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
         // A single tour whose resident runs would not all be on the chip at once (more than two
         // workgroups per CU's worth: a second, mostly empty round) streams instead.
         const bool res_one_round = ntours > 1 || (n + res_P() - 1) / std::max(1, res_P()) <= 2 * ctx->cus;
-        if (res_ok && (res_one_round || !pipe_fits(BT, 64)) && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
+        // A batch of tours (multi-start) over a matrix the last-level cache holds: the streamed kernel with runs of 16 .. 64
+        // edges (below) beats the resident one's 8-edge runs at every size from n = 512 up -- a run's fixed cost (the tour
+        // state derived, the first rows landed: ~4 us) is paid once per 16 .. 64 rows instead of once per 8:
+        // tools/tune_multistart.py, profiles/r03_multistart_plan.txt (pr1002 all starts 94.7 -> 59 ms, n=4096 x 64 330 -> 181 ms,
+        // n=8192 x 32 1579 -> 718 ms; f64 pr1002 x 256 82 -> 45 ms)
+        if (batch_streams && pipe_fits(BT, 64)) kernel = 2;
+        else if (res_ok && (res_one_round || !pipe_fits(BT, 64)) && (ctx->elem == TSPGPU_ELEM_U16 || 9 * row + slack <= ctx->lds_max / 2)) kernel = 3;
         else kernel = pipe_fits(BT, 64) ? 2 : 1;
     }
     if (kernel == 3) {
@@ -3379,6 +3386,13 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
                 k = std::min(k, 2);
                 while (k > 1 && (n + ctx->cus * k - 1) / (ctx->cus * k) < 8) k--;
                 if ((n + ctx->cus * k - 1) / (ctx->cus * k) >= 8) { P = (n + ctx->cus * k - 1) / (ctx->cus * k); G = (n + P - 1) / P; }
+            }
+            if (batch_streams) {
+                // runs of n/64 edges, 16 .. 64 (f64 rows: n/16, 32 .. 256), shorter while the batch has fewer than four
+                // workgroups per CU (the optimum is flat: +-50 % of the run length costs 1-3 %)
+                P = ctx->elem == TSPGPU_ELEM_F64 ? std::min(256, std::max(32, n / 16)) : std::min(64, std::max(16, n / 64));
+                while (P > 8 && (long)ntours * ((n + P - 1) / P) < 4L * ctx->cus) P /= 2;
+                G = (n + P - 1) / P;
             }
             if (ctx->opt_wgs <= 0 && P < 8) {
                 P = std::min(n, 8); G = (n + P - 1) / P;
