@@ -279,6 +279,27 @@ __device__ __forceinline__ int edge_w(double ax, double ay, double bx, double by
 }
 
 
+// The same weight (CEIL_2D, integer coordinates, below 2^22) from INTEGER coordinates, without one f64 instruction -- the
+// matrix-free sweep's form (k_sweep_otf8<KIND_CEIL_INT>): |dx|, |dy| < 2^22 fit the signed 24-bit multipliers
+// (v_mul_i32_i24 / v_mad_i32_i24: full rate, low 32 bits of the 48-bit product), d2 mod 2^32 is all the remainder needs
+// (|e| < 2^24 survives the wrap), and the f32 root may come from an f32 d2: (float)dx is exact, dx*dx and the fused sum
+// cost d2 2^-23 relative, the root 2^-24 (0.25 at 2^22), v_sqrt_f32 one ulp (<= 0.25): within 0.5 of sqrt(d2), so
+// k = floor(r) is floor(sqrt(d2)) - 1, + 0 or + 1 as in edge_w<KIND_CEIL_INT> and the same remainder decides.
+__device__ __forceinline__ int edge_w_ceil_i(int ax, int ay, int bx, int by)
+{
+    const int dx = bx - ax, dy = by - ay;
+    const float fx = (float)dx, fy = (float)dy;
+    const int ki = (int)__builtin_amdgcn_sqrtf(__builtin_fmaf(fy, fy, fx * fx));
+    const int d2lo = __mul24(dx, dx) + __mul24(dy, dy);      // d2 mod 2^32
+    const int e = d2lo - (int)__umul24((unsigned)ki, (unsigned)ki), t1 = 2 * ki + 1;
+    // k is the floor itself nearly always (0 <= e <= 2k): one compare-and-add; the two corrections sit behind a branch a
+    // whole wave rarely takes (measured: the branch-free sum of three comparisons is 7 % slower on pla85900)
+    int r = ki + (int)(e > 0);
+    if (__builtin_expect((unsigned)e > (unsigned)t1, 0))      // e > 2k + 1 or e < 0
+        r = e > 0 ? ki + 2 : (e + t1 <= 2 ? ki - 1 : ki);
+    return r;
+}
+
 // K1 for the integer storages: the weight kind is a template parameter (no branch per cell), the integer weight is
 // produced directly (edge_w: for EUC_2D the correctly rounded f32 root written out, see above), and a workgroup keeps
 // the points of its 256 * V columns in registers while it walks BUILD_ROWS rows -- with one row per workgroup the
@@ -1074,6 +1095,8 @@ struct SweepArgs {
     unsigned long long *stamps; // diagnostics only: 64 wall-clock stamps (10 ns ticks) per workgroup, or null
     const double2 *pts;      // matrix-free mode: node coordinates, and
     const double2 *spts;     //   spts[b] = coordinates of succ b (gathered once per sweep)
+    const int2 *ipts;        // k_sweep_otf8<KIND_CEIL_INT>: the coordinates as integers (offset to the bounding box's corner),
+    const int2 *ispts;       //   and those of succ b
     int kind;                //   edge-weight kind
     const int *tabu_list;    // TABU only
     const TabuState *tabu;   // TABU only
@@ -2449,6 +2472,14 @@ __global__ void __launch_bounds__(256) k_gather_spts(Tours S, int n, int slot0, 
     spts[(size_t)blockIdx.y * n + b] = pts[S.succ[(size_t)t * n + b]];
 }
 
+__global__ void __launch_bounds__(256) k_gather_ispts(Tours S, int n, int slot0, const int2 *__restrict__ ipts, int2 *__restrict__ ispts)
+{
+    const int t = slot0 + blockIdx.y;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n || S.done[t]) return;
+    ispts[(size_t)blockIdx.y * n + b] = ipts[S.succ[(size_t)t * n + b]];
+}
+
 // ---------------------------------------------------------------------------
 // Matrix-free sweep, second form (costs below 2^25, n < 131 072): a thread holds FOUR
 // consecutive b's (their points, the points of their successors, c[b][succ b]: 16-byte loads),
@@ -2464,7 +2495,10 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
 {
     constexpr int RUN = OTF8_RUN, VB = 4, VSH = 2;     // 4 b's per thread: 8 need > 128 registers (two waves per SIMD only)
     __shared__ int nodes_s[RUN + 2];
-    __shared__ double2 npt[RUN + 1];
+    // CEIL_2D on integer coordinates: the points as int2 and the weight without f64 (edge_w_ceil_i)
+    constexpr bool IPT = KIND == KIND_CEIL_INT;
+    typedef typename std::conditional<IPT, int2, double2>::type PT;
+    __shared__ PT npt[RUN + 1];
     __shared__ int dstep[RUN];
     __shared__ Partial scratch[16];
     const int n = A.n;
@@ -2474,8 +2508,13 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     const int *ord = A.S.ord + (size_t)t * n;
     const int *succ = A.S.succ + (size_t)t * n;
     const int *dnb = dnb_of<int>(A.S, t, n);
-    const double2 *pts = A.pts;
-    const double2 *spts = A.spts + (size_t)blockIdx.y * n;
+    const PT *pts, *spts;
+    if constexpr (IPT) { pts = A.ipts; spts = A.ispts + (size_t)blockIdx.y * n; }
+    else { pts = A.pts; spts = A.spts + (size_t)blockIdx.y * n; }
+    auto weight = [](const PT &u, const PT &v) __attribute__((always_inline)) {
+        if constexpr (IPT) return edge_w_ceil_i(u.x, u.y, v.x, v.y);
+        else return edge_w<KIND>(u.x, u.y, v.x, v.y);
+    };
     const int dir = A.S.dir[t];
     int *nodes = nodes_s + 1;
 
@@ -2503,7 +2542,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
         const int w0 = base + wave_lane0 * VB;           // this wave's first b
         if (w0 >= n) continue;
         const int b0 = base + tid * VB;
-        double2 pb[VB], sp[VB];
+        PT pb[VB], sp[VB];
         int dn[VB];
         unsigned skm = 0;
 #pragma unroll
@@ -2529,13 +2568,13 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
             if (!self && !(2 * d < NB || (2 * d == NB && a / (64 * VB) < blkb))) continue;   // the other orientation's
             const bool hit = TABU && ((unsigned)(am - w0) < (unsigned)(64 * VB) || (unsigned)(sa - w0) < (unsigned)(64 * VB));
             const bool clean = !self && !hit && w0 + 64 * VB <= n;
-            const double2 pa = npt[s], ps = npt[s + 1];
+            const PT pa = npt[s], ps = npt[s + 1];
             auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
                 constexpr bool CHECK = decltype(check_tag)::value;
                 int m = 0x7fffffff;
 #pragma unroll
                 for (int v = 0; v < VB; v++) {
-                    int dl = edge_w<KIND>(pa.x, pa.y, pb[v].x, pb[v].y) + edge_w<KIND>(ps.x, ps.y, sp[v].x, sp[v].y) - dn[v];
+                    int dl = weight(pa, pb[v]) + weight(ps, sp[v]) - dn[v];
                     if constexpr (CHECK) {
                         const int b = b0 + v;
                         const bool ok = ((b > a) | !self) & (b < n) & (!TABU | ((b != am) & (b != sa)));
@@ -2917,6 +2956,7 @@ struct tspgpu_ctx {
     bool otf = false;        // matrix-free: weights recomputed from d_pts
     int opt_otf = 0;         // 0 auto, 1 force matrix-free, 2 never
     double2 *d_spts = nullptr; size_t spts_cap = 0;
+    int2 *d_ipts = nullptr;  // ceil_int(): the coordinates as integers relative to the bounding box's corner (k_sweep_otf8<KIND_CEIL_INT>)
     // uniform grid over the points for the grid NN (k_nn_grid): built on the host in tspgpu_set_points
     double2 *d_gxy = nullptr; int *d_gidx = nullptr, *d_gpos = nullptr, *d_cstart = nullptr, *d_gcell = nullptr;
     unsigned *d_knn = nullptr;   // [n][NN_K] neighbour lists of k_nn_grid's KNN form (built at the first single-tour NN)
@@ -3449,7 +3489,12 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
     A.tabu_list = ctx->d_tabu_list; A.tabu = ctx->d_tabu;
     if (ctx->plan_kernel == 4) {
         const int n = ctx->n;
-        hipLaunchKernelGGL(k_gather_spts, dim3((n + 255) / 256, ntours), dim3(256), 0, ctx->stream, ctx->S, n, slot0, ctx->d_pts, ctx->d_spts);
+        const bool otf8 = ctx->cost_bound < 33554432.0 && n < 131072;
+        if (otf8 && ctx->ceil_int() && ctx->d_ipts) {      // (the int2 successors' points take the front half of the double2 buffer)
+            A.ipts = ctx->d_ipts; A.ispts = reinterpret_cast<const int2 *>(ctx->d_spts);
+            hipLaunchKernelGGL(k_gather_ispts, dim3((n + 255) / 256, ntours), dim3(256), 0, ctx->stream, ctx->S, n, slot0, ctx->d_ipts, reinterpret_cast<int2 *>(ctx->d_spts));
+        } else
+            hipLaunchKernelGGL(k_gather_spts, dim3((n + 255) / 256, ntours), dim3(256), 0, ctx->stream, ctx->S, n, slot0, ctx->d_pts, ctx->d_spts);
         HIP_TRY(hipGetLastError());
         const void *fo = tabu ? (const void *)k_sweep_otf<true> : (const void *)k_sweep_otf<false>;
         if (ctx->cost_bound < 33554432.0 && n < 131072) {     // 2^25, 17-bit labels
@@ -4373,6 +4418,7 @@ void tspgpu_destroy(tspgpu_ctx *ctx)
     if (ctx->d_trace) hipFree(ctx->d_trace);
     if (ctx->d_stamps) hipFree(ctx->d_stamps);
     if (ctx->d_spts) hipFree(ctx->d_spts);
+    if (ctx->d_ipts) hipFree(ctx->d_ipts);
     free_grid(ctx);
     if (ctx->hist.a) { hipFree(ctx->hist.a); hipFree(ctx->hist.b); hipFree(ctx->hist.d); }
     for (auto e : ctx->ev) hipEventDestroy(e);
@@ -4491,6 +4537,13 @@ int tspgpu_set_points(tspgpu_ctx *ctx, const double *xy, int n, int edge_weight_
     }
     const double diag = std::sqrt((x1 - x0) * (x1 - x0) + (y1 - y0) * (y1 - y0));
     ctx->cost_bound = (edge_weight_type == TSPGPU_ATT ? diag / std::sqrt(10.0) : diag) + 2.0;
+    if (ctx->d_ipts) { hipFree(ctx->d_ipts); ctx->d_ipts = nullptr; }
+    if (ctx->ceil_int()) {
+        std::vector<int> ip((size_t)2 * n);
+        for (int i = 0; i < n; i++) { ip[2 * i] = (int)(xy[2 * i] - x0); ip[2 * i + 1] = (int)(xy[2 * i + 1] - y0); }
+        HIP_TRY(hipMalloc(&ctx->d_ipts, (size_t)n * sizeof(int2)));
+        HIP_TRY(hipMemcpy(ctx->d_ipts, ip.data(), (size_t)n * sizeof(int2), hipMemcpyHostToDevice));
+    }
     return build_grid(ctx, xy, n, x0, x1, y0, y1);
 }
 
