@@ -42,7 +42,7 @@ def count(text, kind):
     i = text.index("\n" + name + ":")
     j = text.index(".Lfunc_end", i)
     # the step loop (RUN = 16 tour edges per workgroup) is a real loop since round 3: the pair evaluations are the basic
-    # blocks at loop depth 2 -- {unmasked, masked} x 4 b's per thread = 8 static pairs; a fully unrolled kernel (round 2:
+    # blocks at loop depth 2 -- {unmasked, masked} x 4 b's per thread (8 with integer points) = 8 (16) static pairs; a fully unrolled kernel (round 2:
     # RUN = 8) has no depth-2 blocks and is counted whole, 64 static pairs
     ops_all, ops_in = collections.Counter(), collections.Counter()
     depth = 0
@@ -62,7 +62,7 @@ def count(text, kind):
         if depth >= 2:
             ops_in[t.split()[0]] += 1
     rolled = sum(v for k, v in ops_in.items() if k.startswith("v_")) > 0
-    ops, pairs = (ops_in, 8) if rolled else (ops_all, STATIC_PAIRS)
+    ops, pairs = (ops_in, 2 * (8 if kind == 3 else 4)) if rolled else (ops_all, STATIC_PAIRS)      # {unmasked, masked} x b's per thread
     valu = {k: v for k, v in ops.items() if k.startswith("v_")}
     cycles = sum(price(k) * v for k, v in valu.items())
     n_valu = sum(valu.values())

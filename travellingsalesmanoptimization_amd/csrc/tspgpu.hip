@@ -2493,7 +2493,8 @@ constexpr int OTF8_RUN = 16;        // tour edges per workgroup: the per-b array
 template <int KIND, bool TABU>
 __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
 {
-    constexpr int RUN = OTF8_RUN, VB = 4, VSH = 2;     // 4 b's per thread: 8 need > 128 registers (two waves per SIMD only)
+    // 4 b's per thread with double2 points (8 need > 128 registers: two waves per SIMD only); 8 with int2 points
+    constexpr int RUN = OTF8_RUN, VB = KIND == KIND_CEIL_INT ? 8 : 4, VSH = KIND == KIND_CEIL_INT ? 3 : 2;
     __shared__ int nodes_s[RUN + 2];
     // CEIL_2D on integer coordinates: the points as int2 and the weight without f64 (edge_w_ceil_i)
     constexpr bool IPT = KIND == KIND_CEIL_INT;
