@@ -543,9 +543,15 @@ def main():
             t1 = time.perf_counter()
             res = eng.multistart_nn_2opt(starts)
             dtb = time.perf_counter() - t1
+            bpe = 2 * BYTES[eng.info()["elem"]]
             return {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
                     "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"],
-                    "includes": "NN construction + 2-opt of every start, host arrays in/out"}
+                    "includes": "NN construction + 2-opt of every start, host arrays in/out",
+                    # SURVEY 8(d)'s convention for the streamed kernels: 2 matrix cells per evaluation / time / the HBM peak.  The
+                    # tours of a batch share one matrix, so part of these bytes are last-level-cache hits: a nominal fraction
+                    "nominal_hbm": {"bytes_per_eval": bpe, "achieved_GBs": res["sweeps"] * evals * bpe / dtb / 1e9,
+                                    "peak_GBs": HBM_PEAK_GBS, "frac": res["sweeps"] * evals * bpe / dtb / 1e9 / HBM_PEAK_GBS,
+                                    "kernel": "k_sweep_pipe (rows streamed, runs of n/64 edges)"}}
         batch = guarded(batch_leg)
 
     # ---- the other rows of north_star's throughput table (n = 1k / 16k), each on its own engine
