@@ -19,6 +19,8 @@ nstarts = int(sys.argv[2]) if len(sys.argv) > 2 else n
 starts = np.arange(nstarts, dtype=np.int32)
 eng = T.Engine(0)
 eng.set_option(T.OPT_ELEM, int(os.environ.get("ELEM", "0")))
+if os.environ.get("DEPTH"):
+    eng.set_option(T.OPT_DEPTH, int(os.environ["DEPTH"]))      # rows in flight per thread in the streamed kernel
 eng.set_points(xy, kind); eng.build_costs()
 combos = [(0, 0, 0), (3, 0, 0), (2, 0, 0)] + [(2, max(1, n // p), 0) for p in (8, 12, 16, 24, 32, 48, 64, 128)]
 if len(sys.argv) > 3:
