@@ -395,13 +395,17 @@ double orc_tour_cost_xy(const double *xy, int n, int kind, const int *succ)
     return s;
 }
 
-double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double *cost, int *move_ab)
+/* the scan of refinment.c:49-69 restricted to a in [a_lo, a_hi) -- read-only, so that a test can spread one sweep of a
+ * large matrix-free instance over host threads (pla85900: 3.7e9 pairs); the first strictly smallest delta in (a asc, b asc)
+ * order of the slice; the caller combines slices in ascending a with a strict < (= the sequential result) */
+double orc_two_opt_scan_xy(const double *xy, int n, int kind, const int *succ, int a_lo, int a_hi, int *move_ab)
 {
     double best = 0;
     int ba = -1, bb = -1;
     double *dn = (double *)malloc(sizeof(double) * (size_t)n);   /* c[b][succ b] */
     for (int b = 0; b < n; b++) dn[b] = edge_weight(xy[2 * b], xy[2 * b + 1], xy[2 * succ[b]], xy[2 * succ[b] + 1], kind);
-    for (int a = 0; a < n - 1; a++) {
+    if (a_hi > n - 1) a_hi = n - 1;
+    for (int a = a_lo < 0 ? 0 : a_lo; a < a_hi; a++) {
         const int sa = succ[a];
         const double ax = xy[2 * a], ay = xy[2 * a + 1], sx = xy[2 * sa], sy = xy[2 * sa + 1];
         for (int b = a + 1; b < n; b++) {
@@ -415,6 +419,15 @@ double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double 
         }
     }
     free(dn);
+    if (move_ab) { move_ab[0] = ba; move_ab[1] = bb; }
+    return best;
+}
+
+double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double *cost, int *move_ab)
+{
+    int ab[2];
+    const double best = orc_two_opt_scan_xy(xy, n, kind, succ, 0, n - 1, ab);
+    const int ba = ab[0], bb = ab[1];
     if (move_ab) { move_ab[0] = ba; move_ab[1] = bb; }
     if (best < ORC_EPS) {
         int *prev = (int *)malloc(sizeof(int) * (size_t)n);

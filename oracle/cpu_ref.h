@@ -94,6 +94,8 @@ int orc_vns(const double *c, int n, int *succ, double *cost, int k,
 int orc_nn_tour_xy(const double *xy, int n, int kind, int start, int *succ, double *cost);
 double orc_tour_cost_xy(const double *xy, int n, int kind, const int *succ);
 double orc_two_opt_once_xy(const double *xy, int n, int kind, int *succ, double *cost, int *move_ab);
+/* the scan of one sweep for a in [a_lo, a_hi), read-only (refinment.c:49-69) */
+double orc_two_opt_scan_xy(const double *xy, int n, int kind, const int *succ, int a_lo, int a_hi, int *move_ab);
 
 /* src/tsp.c:642-667 + :687-728  tsp_validate_solution / tsp_is_tour. */
 int orc_valid_tour(const int *succ, int n);

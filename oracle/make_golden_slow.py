@@ -9,6 +9,10 @@ per case under tests/golden/ (authoring container only; needs /root/reference fo
     python oracle/make_golden_slow.py mod_costs_threads   # seconds: h_Greedy_2opt_mod_costs on four caller
         matrices per instance (the concurrency test of the host layer)
 
+    python oracle/make_golden_slow.py n4096_multistart [count [procs]]   # ~10 min per 64 starts on 6 cores: -n 4096
+        -seed 123 (the headline instance), NN + ref_2opt to the local optimum from starts 0..count-1 (gate of the
+        batched multi-start legs of bench.py: 64 starts on one GPU, the 512-start job sharded over N); incremental
+
 The outputs are DATA (costs, sweep counts, FNV-1a of successor arrays).
 """
 import json
@@ -65,6 +69,38 @@ def n16384():
     json.dump(out, open(os.path.join(ROOT, "tests", "golden", "golden_n16384_s123.json"), "w"), indent=1)
 
 
+def _n4096_one(s):
+    ref = O.Reference(scratch=os.path.join(HERE, "_ref", f"scratch_{s}"))
+    ref.random(4096, 123)
+    succ, nn_cost, _ = ref.nn(s)
+    nn_fnv = O.fnv1a(succ)
+    sweeps, cost, _ = ref.two_opt_counted(succ, -1, 0)
+    return {"start": s, "nn_cost": nn_cost, "nn_fnv": f"{nn_fnv:016x}", "sweeps": sweeps, "cost": cost,
+            "fnv": f"{O.fnv1a(succ):016x}"}
+
+
+def n4096_multistart(count=64, procs=6):
+    """h_greedy_2opt's loop body (heuristics.c:82-111) for starts 0..count-1 of the headline instance, one
+    reference process per start (the reference keeps its instance in process-wide globals); starts already in
+    the file are kept (the runs are independent), so the fixture can be extended"""
+    import multiprocessing as mp
+    t0 = time.time()
+    path = os.path.join(ROOT, "tests", "golden", "golden_n4096_multistart.json")
+    have = {e["start"]: e for e in json.load(open(path))["starts"]} if os.path.exists(path) else {}
+    todo = [s for s in range(count) if s not in have]
+    with mp.get_context("spawn").Pool(procs) as pool:
+        for e in pool.imap_unordered(_n4096_one, todo, chunksize=1):
+            have[e["start"]] = e
+            print(e["start"], e["cost"], round(time.time() - t0), flush=True)
+    starts = [have[s] for s in sorted(have)]
+    best = min(starts, key=lambda e: (e["cost"], e["start"]))   # strict <, ascending starts (tsp.c:671)
+    out = {"_generator": "oracle/make_golden_slow.py n4096_multistart (reference compiled by oracle/Makefile)",
+           "n": 4096, "seed": 123, "starts": starts,
+           "best": {"start": best["start"], "cost": best["cost"], "fnv": best["fnv"]},
+           "total_sweeps": sum(e["sweeps"] for e in starts)}
+    json.dump(out, open(path, "w"), indent=1)
+
+
 def mod_costs_matrix(c, seed):
     """the shape cplex_model.c:1176-1258 feeds h_Greedy_2opt_mod_costs: c[i][j] * (1 - x*_ij), symmetric,
     non-integer, diagonal 0 (same construction as oracle/make_golden.py)"""
@@ -98,4 +134,6 @@ def mod_costs_threads():
 
 
 if __name__ == "__main__":
-    {"d18512_multistart": d18512_multistart, "n16384": n16384, "mod_costs_threads": mod_costs_threads}[sys.argv[1]]()
+    fn = {"d18512_multistart": d18512_multistart, "n16384": n16384, "mod_costs_threads": mod_costs_threads,
+          "n4096_multistart": n4096_multistart}[sys.argv[1]]
+    fn(*[int(a) for a in sys.argv[2:]])

@@ -61,6 +61,8 @@ def lib():
         L.orc_tour_cost_xy.restype = C.c_double
         L.orc_two_opt_once_xy.argtypes = [_dp, C.c_int, C.c_int, _ip, C.POINTER(C.c_double), _ip]
         L.orc_two_opt_once_xy.restype = C.c_double
+        L.orc_two_opt_scan_xy.argtypes = [_dp, C.c_int, C.c_int, _ip, C.c_int, C.c_int, _ip]
+        L.orc_two_opt_scan_xy.restype = C.c_double
         L.orc_valid_tour.argtypes = [_ip, C.c_int]
         L.orc_fnv1a.argtypes = [_ip, C.c_int]
         L.orc_fnv1a.restype = C.c_uint64
@@ -211,6 +213,31 @@ def two_opt_once_xy(xy, kind, succ, cost):
     mv = np.empty(2, dtype=np.int32)
     d = lib().orc_two_opt_once_xy(xy, len(xy) // 2, kind, succ, C.byref(cc), mv)
     return d, cc.value, (int(mv[0]), int(mv[1]))
+
+
+def two_opt_best_move_xy(xy, kind, succ, threads=8):
+    """One sweep's best move WITHOUT applying it, the scan spread over host threads (ctypes drops the GIL):
+    slices of a with equal pair counts, combined in ascending a with a strict < -- the sequential result of
+    refinment.c:49-69.  Returns (delta, (a, b)); delta >= -1e-7 certifies a 2-opt local optimum."""
+    from concurrent.futures import ThreadPoolExecutor
+    xy = np.ascontiguousarray(xy, dtype=np.float64).reshape(-1)
+    n = len(xy) // 2
+    succ = np.ascontiguousarray(succ, np.int32)
+    parts = max(1, threads * 4)
+    # row a holds n-1-a pairs: cut the triangle into slices of equal area
+    cuts = sorted({int(round(n - 1 - (n - 1) * np.sqrt(1.0 - i / parts))) for i in range(parts + 1)} | {0, n - 1})
+
+    def scan(lo, hi):
+        mv = np.empty(2, dtype=np.int32)
+        d = lib().orc_two_opt_scan_xy(xy, n, kind, succ, lo, hi, mv)
+        return d, int(mv[0]), int(mv[1])
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        res = list(ex.map(lambda lh: scan(*lh), zip(cuts[:-1], cuts[1:])))
+    best = (0.0, -1, -1)
+    for d, a, b in res:
+        if d < best[0]:
+            best = (d, a, b)
+    return best[0], (best[1], best[2])
 
 
 def valid_tour(succ):

@@ -247,6 +247,36 @@ def test_nn_all_golden(eng, T, O, instances, golden):
         assert (cost, start, fx(O, succ)) == (g["cost"], g["starting_node"], g["fnv"])
 
 
+def _published():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "published_heuristics_ric.json")))["instances"]
+
+
+@pytest.mark.parametrize("name", sorted(_published()))
+def test_published_nn_columns_engine(eng, T, O, name):
+    """the reference's own published deterministic numbers (results/heuristics-ric.csv:2-15, columns NN and allNN; 14
+    instances, six with non-integer coordinates, fl1400 / fl1577 heavily clustered -- the cases the grid kernel's
+    expansion rule and tie-breaks have to survive, heuristics.c:253-263) through the engine: tspgpu_nn_tour(0) and
+    tspgpu_nn_all, with the grid kernel (with and without the neighbour lists) and the matrix kernel, over a matrix
+    and matrix-free"""
+    want = _published()[name]
+    xy, ewt = O.read_tsplib(data_path(name))
+    assert ewt == "EUC_2D"
+    try:
+        for mf in (2, 1):
+            eng.set_option(T.OPT_MATRIX_FREE, mf); eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+            eng.set_points(xy); eng.build_costs()
+            for nnk in (0, 3, 1):            # 0: grid + neighbour lists where they fit, 3: grid alone, 1: matrix / strided
+                eng.set_option(T.OPT_NN_KERNEL, nnk)
+                assert (eng.info()["nn_grid"] > 0) == (nnk != 1), (eng.info(), nnk)
+                succ, cost = eng.nn_tour(0)
+                assert cost == want["NN"] and O.valid_tour(succ), (mf, nnk)
+                best, bcost, bstart = eng.nn_all()
+                assert bcost == want["allNN"] and O.valid_tour(best), (mf, nnk)
+    finally:
+        eng.set_option(T.OPT_NN_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+
+
 # ------------------------------------------------------------------ K2/K4 sweeps
 @pytest.fixture(params=[2, 0], ids=["fused", "split"])
 def fused(request, eng, T):
@@ -730,6 +760,35 @@ def test_multistart_pr1002_all_starts(eng, T, O, instances, golden):
     assert O.valid_tour(res["path"])
 
 
+def test_multistart_batch_n4096_headline_golden(eng, T, O):
+    """the throughput-regime number of bench.py (`multistart_batch`: the headline instance -n 4096 -seed 123, All-NN+2OPT
+    over a batch of starts, k_sweep_pipe with 64-edge runs -- VERDICT r3 missing 5) against the COMPILED REFERENCE
+    (tests/golden/golden_n4096_multistart.json, oracle/make_golden_slow.py n4096_multistart: h_greedyutil + ref_2opt per
+    start, heuristics.c:82-111): every start's final cost and tour hash (read back from its slot), the sweep total, the
+    winner (strict <, ascending starts: tsp.c:671) -- for the first 8 starts, for all of the golden's, and for a shard
+    (every 4th start: what one of four ranks runs)"""
+    import json, os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_n4096_multistart.json")))
+    xy = O.random_points(g["n"], g["seed"])
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+    eng.set_points(xy); eng.build_costs()
+    by_start = {e["start"]: e for e in g["starts"]}
+    all_starts = sorted(by_start)
+    assert len(all_starts) >= 64
+    for starts in (all_starts[:8], all_starts, all_starts[1::4]):
+        res = eng.multistart_nn_2opt(np.array(starts, dtype=np.int32))
+        info = eng.info()
+        assert res["rc"] == 0 and info["kernel"] == 2 and info["elem"] == 3, info       # k_sweep_pipe over uint16 cells
+        want = [by_start[s] for s in starts]
+        best = min(want, key=lambda e: (e["cost"], e["start"]))
+        assert (res["cost"], res["start"], fx(O, res["path"])) == (best["cost"], best["start"], best["fnv"])
+        assert res["sweeps"] == sum(e["sweeps"] for e in want)
+        for slot, e in enumerate(want):
+            p, c, _ = eng.tour_store(slot)
+            assert (c, fx(O, p)) == (e["cost"], e["fnv"]), (slot, e["start"])
+    assert g["best"] == {k: min(g["starts"], key=lambda e: (e["cost"], e["start"]))[k] for k in ("start", "cost", "fnv")}
+
+
 def test_multistart_subset_and_chunks(eng, T, O, instances):
     xy, c = setup(eng, T, O, instances, "n200_s3", 0)
     starts = np.array([7, 199, 0, 33, 34, 150, 3], dtype=np.int32)
@@ -1016,6 +1075,70 @@ def test_pla85900_config5(eng, T, O):
         assert (int(a[i]), int(b[i]), float(d[i])) == (m["a"], m["b"], m["delta"])
     assert cost == g["moves"][-1]["cost"] and fx(O, succ) == g["moves"][-1]["fnv"]
     assert O.valid_tour(succ)
+
+
+def test_pla85900_config5_local_optimum_and_vns(eng, T, O, capsys):
+    """BASELINE config 5 end to end on its own engine (VERDICT r3 missing 2): pla85900 (CEIL_2D, n = 85 900, on-the-fly
+    distances) NN(0) -> 2-opt LOCAL OPTIMUM (refinment.c:3-37; ~12 k sweeps of k_sweep_otf8), certified by the oracle:
+    valid tour, cost = the oracle's node-order recomputation, and ONE full oracle sweep (3.7e9 pairs, spread over host
+    threads) finds no improving pair.  Then mh_VNS's loop from that optimum (metaheuristic.c:279-318, :344-409):
+    iteration 0 = ref_2opt (nothing to do) + r kicks on fixed rand() values -- the kicked tour equals the oracle's
+    vns_kick on the same tour and numbers, `consumed` matches --, iteration 1 = the repair descent, certified the same
+    way."""
+    import ctypes, time
+    xy, ewt = O.read_tsplib(data_path("pla85900"))
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
+    eng.set_points(xy, O.CEIL_2D); eng.build_costs()
+    n = eng.n
+    assert eng.info()["matrix_free"] == 1
+    eng.tour_nn(0, 0)
+    t0 = time.time()
+    sweeps, rc = eng.tour_two_opt(0)
+    dt = time.time() - t0
+    opt, cost, _ = eng.tour_store(0)
+    assert rc == 0 and eng.info()["kernel"] == 4
+    assert O.valid_tour(opt) and O.tour_cost_xy(xy, O.CEIL_2D, opt) == cost
+    d, mv = O.two_opt_best_move_xy(xy, O.CEIL_2D, opt, threads=16)
+    assert d >= -1e-7, (d, mv)                                   # a 2-opt local optimum by the reference's own scan
+    with capsys.disabled():
+        print(f"\n[pla85900 matrix-free] NN(0) -> local optimum: {sweeps} sweeps, {dt:.1f} s, cost {cost:.0f}, "
+              f"{sweeps * T.evals_per_sweep(n) / dt:.3e} evals/s all in")
+    # ---- a seed of the glibc stream whose first iteration kicks (r >= 2) and whose second does not (r <= 0)
+    libc = ctypes.CDLL(None)
+    for seed in range(1, 200):
+        O.libc_srand(seed)
+        r0 = libc.rand() % 9 - 2
+        if r0 < 2:
+            continue
+        kicked = opt.copy()
+        for _ in range(r0):
+            O.vns_kick(kicked)
+        nxt = libc.rand()
+        if nxt % 9 - 2 <= 0:
+            break
+    else:
+        pytest.fail("no seed found")
+    rv = _libc_draws(O, seed, 4096)
+    used0 = int(np.nonzero(rv == nxt)[0][0])                      # numbers iteration 0 consumes: 1 + the kicks' draws
+    assert used0 >= 1 + 3 * r0 and not np.array_equal(kicked, opt) and O.valid_tour(kicked)
+    # ---- iteration 0 on the engine: local search (already optimal: one sweep), incumbent, kicks
+    path, best = opt.copy(), opt.copy()
+    r = eng.vns_search(path, 1, rv, best, cost, want_trace=True)
+    assert (r["rc"], r["iterations"], r["kick_pending"]) == (0, 1, 0) and eng.info()["matrix_free"] == 1
+    assert r["consumed"] == used0 and np.array_equal(path, kicked)
+    assert r["best_cost"] == cost and np.array_equal(best, opt) and r["trace"][0] == cost
+    # ---- iteration 1: the repair descent (then r <= 0: no kick), certified like the first optimum
+    t0 = time.time()
+    r = eng.vns_search(path, 2, rv[used0:], best, r["best_cost"], iterations=1, want_trace=True)
+    dt = time.time() - t0
+    assert (r["rc"], r["iterations"], r["kick_pending"], r["consumed"]) == (0, 2, 0, 1)
+    assert O.valid_tour(path) and O.tour_cost_xy(xy, O.CEIL_2D, path) == r["cost"] == r["trace"][0]
+    d, mv = O.two_opt_best_move_xy(xy, O.CEIL_2D, path, threads=16)
+    assert d >= -1e-7, (d, mv)
+    assert r["best_cost"] == min(cost, r["cost"]) and np.array_equal(best, path if r["cost"] < cost else opt)
+    with capsys.disabled():
+        print(f"[pla85900 matrix-free] VNS iteration: {r0} kicks ({used0} numbers), repair descent {dt:.2f} s -> {r['cost']:.0f} "
+              f"(first optimum {cost:.0f})")
 
 
 # ------------------------------------------------------------------ the LDS-resident descent (k_lds2opt)
@@ -1462,6 +1585,80 @@ def test_vns_search_against_the_oracle(eng, T, O, instances, name, k, mode):
         assert len(tr) == k and tr.min() == obc and not np.isnan(tr).any()
     finally:
         eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_PERSIST_WINDOW, 0)
+
+
+def _mf_instance(O, instances, name):
+    """(xy, weight kind, oracle matrix) of the matrix-free walk tests: EUC_2D fixtures, CEIL_2D on integer coordinates up to
+    1.5e6 (the integer ceil-sqrt weight of k_sweep_otf8<KIND_CEIL_INT>, pla85900's kind), ATT"""
+    if name == "ceil_int1e6":
+        xy = np.random.RandomState(3).randint(0, 1500000, size=(700, 2)).astype(np.float64)
+        return xy, O.CEIL_2D, O.cost_matrix(xy, O.CEIL_2D)
+    if name == "att_kroA100":
+        xy = instances("kroA100")[0]
+        return xy, O.ATT, O.cost_matrix(xy, O.ATT)
+    xy, c = instances(name)
+    return xy, O.EUC_2D, c
+
+
+@pytest.mark.parametrize("name,k", [("kroA100", 200), ("n200_s3", 150), ("pr1002", 40), ("n1000_s123", 40), ("ceil_int1e6", 60),
+                                    ("att_kroA100", 100)])
+def test_vns_search_matrix_free(mf, T, O, instances, name, k):
+    """BASELINE config 5's algorithm on config 5's engine (VERDICT r3 missing 2): mh_VNS's loop
+    (metaheuristic.c:279-318) over ON-THE-FLY distances -- no n x n matrix; every local search in k_sweep_otf8, the kicks
+    on the host (vns_kick_host) -- against the oracle on the same glibc stream: the incumbent, its cost, the final
+    (kicked) tour, the cost of every local optimum and the number of rand() values consumed; EUC_2D, CEIL_2D on integer
+    coordinates (pla85900's weight kind) and ATT"""
+    xy, kind, c = _mf_instance(O, instances, name)
+    mf.set_points(xy, kind); mf.build_costs()
+    assert mf.info()["matrix_free"] == 1
+    seed0, cost0 = O.nn_tour(c, 7)
+    rv = _libc_draws(O, 5, 64 * k + 4096)
+    obest, obc, ofinal, oused = _oracle_vns(O, c, seed0, cost0, k, 5, rv)
+    path, best = seed0.copy(), seed0.copy()
+    r = mf.vns_search(path, k, rv, best, cost0, want_trace=True)
+    info = mf.info()
+    assert info["matrix_free"] == 1 and info["kernel"] == 4 and info["persist"] == 0
+    assert (r["rc"], r["iterations"], r["kick_pending"]) == (0, k, 0)
+    assert r["best_cost"] == obc and np.array_equal(best, obest)
+    assert np.array_equal(path, ofinal) and r["consumed"] == oused
+    assert O.valid_tour(best) and O.tour_cost(c, best) == obc
+    tr = r["trace"]
+    assert len(tr) == k and tr.min() == obc and not np.isnan(tr).any()
+    # ... and refilled a few numbers at a time (code 8 in front of a kick phase) it reaches the same result
+    path, best = seed0.copy(), seed0.copy()
+    it = kp = 0
+    bc, used = cost0, 0
+    for give in (3, 5, 1, 40, 7, 100000):
+        r = mf.vns_search(path, k, rv[used:used + give], best, bc, iterations=it, kick_pending=kp)
+        it, kp, bc = r["iterations"], r["kick_pending"], r["best_cost"]
+        used += r["consumed"]
+        if r["rc"] == 0:
+            break
+        assert r["rc"] == 8 and kp == 1 and it < k
+    assert (it, kp) == (k, 0) and bc == obc and np.array_equal(best, obest) and np.array_equal(path, ofinal) and used == oused
+
+
+@pytest.mark.parametrize("name,k", [("kroA100", 400), ("n200_s3", 400), ("pr1002", 200), ("ceil_int1e6", 150)])
+def test_tabu_walk_matrix_free(mf, T, O, instances, name, k):
+    """mh_TabuSearch's k iterations (metaheuristic.c:115-166; tabu_best_move :188-245) over on-the-fly distances
+    (k_sweep_otf8<., TABU> + k_apply): from the 2-opt local optimum of NN(0) the cost after EVERY iteration, the final
+    tour, the best tour and its cost equal the oracle's"""
+    xy, kind, c = _mf_instance(O, instances, name)
+    mf.set_points(xy, kind); mf.build_costs()
+    assert mf.info()["matrix_free"] == 1
+    seed, cost = O.nn_tour(c, 0)
+    O.two_opt(c, seed)
+    cost = O.tour_cost(c, seed)
+    oseed = seed.copy()
+    best, best_cost, final, trace = mf.tabu_search(seed, cost, k, want_trace=True)
+    info = mf.info()
+    assert info["matrix_free"] == 1 and info["persist"] == 0
+    obest, obc, ofinal, otrace = O.tabu_search(c, oseed, cost, k)
+    bad = np.nonzero(trace != otrace)[0]
+    assert len(bad) == 0, (bad[:5], trace[bad[:5]], otrace[bad[:5]])
+    assert final == ofinal and np.array_equal(seed, oseed)
+    assert best_cost == obc and np.array_equal(best, obest)
+    assert O.valid_tour(best) and O.tour_cost(c, best) == best_cost
 
 
 @pytest.mark.parametrize("mode", ["resident", "host_kicks"])

@@ -4,8 +4,10 @@ reference's test/main.c:13-69, which no longer compile there) and loud failure w
 GPU.  GPU part: the `tsp` binary's -q stdout contract against the golden costs, the way
 scripts/compare_algs.py:67-72 drives the reference."""
 import ctypes as C
+import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -117,6 +119,20 @@ def test_binary_greedy_and_iter(golden, name):
         assert out == "Cost: %.2f" % golden["algs"][f"{name}_{key}"]["cost"]   # compare_algs.py:72 scrapes this
 
 
+PUBLISHED = json.load(open(os.path.join(ROOT, "tests", "golden", "published_heuristics_ric.json")))["instances"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(PUBLISHED))
+def test_binary_published_nn_columns(name):
+    """what scripts/compare_algs.py:67-72 did to fill results/heuristics-ric.csv (columns NN, allNN): `tsp -f <instance>
+    -alg GREEDY | GREEDY_ITER -q` and the number behind "Cost:" -- all 28 published values, from the drop-in binary"""
+    for alg, col in [("GREEDY", "NN"), ("GREEDY_ITER", "allNN")]:
+        rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", alg)
+        assert rc == 0, err
+        assert out == "Cost: %.2f" % PUBLISHED[name][col]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002"])
 def test_binary_2opt_greedy(golden, name):
@@ -134,6 +150,19 @@ def test_binary_tabu_and_vns(golden, name, tmp_path):
     lines = open(os.path.join(ROOT, "results", "TabuResults.dat")).read().split()
     assert len(lines) == 200 and lines[0].startswith("0,")                       # metaheuristic.c:165
     rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "VNS", "-k", "200")
+    assert rc == 0 and out == "Cost: %.2f" % golden["algs"][f"{name}_vns_k200"]["cost"], err
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100"])
+def test_binary_tabu_and_vns_matrix_free(golden, name):
+    """the same runs with TSP_MATRIX_FREE=1 -- BASELINE config 5's engine (no n x n matrix, tsp_inst.costs NULL, every local
+    search in the on-the-fly sweep) under mh_TabuSearch and mh_VNS -- against the compiled reference's goldens"""
+    os.makedirs(os.path.join(ROOT, "results"), exist_ok=True)
+    env = {"TSP_MATRIX_FREE": "1"}
+    rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "TABU_SEARCH", "-k", "200", env=env)
+    assert rc == 0 and out == "Cost: %.2f" % golden["algs"][f"{name}_tabu_k200"]["cost"], err
+    rc, out, err = run_q("-f", os.path.join(DATA, name + ".tsp"), "-alg", "VNS", "-k", "200", env=env)
     assert rc == 0 and out == "Cost: %.2f" % golden["algs"][f"{name}_vns_k200"]["cost"], err
 
 
@@ -350,6 +379,59 @@ def test_vns_kick_matches_the_oracle_at_any_size(host, O, n):
     for _ in range(25):
         assert host.vns_kick(C.byref(sol)) == 0
     assert np.array_equal(got, want) and O.valid_tour(got)
+
+
+def kick_oob_cycle(n):
+    """the seeded random cycle of tests/golden/golden_kick_oob.json (its "cycle" entry; oracle/ref_kick_probe.c)"""
+    import numpy as np
+    order, x, m = list(range(n)), (0x9E3779B97F4A7C15 ^ n) & (2 ** 64 - 1), 2 ** 64 - 1
+    for i in range(n - 1, 0, -1):
+        x = (x * 6364136223846793005 + 1442695040888963407) & m
+        j = (x >> 33) % (i + 1)
+        order[i], order[j] = order[j], order[i]
+    o = np.array(order, dtype=np.int32)
+    succ = np.empty(n, dtype=np.int32)
+    succ[o] = np.roll(o, -1)
+    return succ
+
+
+KICK_OOB = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_kick_oob.json")))
+
+
+@pytest.mark.parametrize("case", [c for c in KICK_OOB["cases"] if c["mode"] == "warm"], ids=lambda c: str(c["n"]))
+def test_vns_kick_against_the_compiled_reference_at_large_n(host, O, case):
+    """the model of vns_kick's out-of-range probes (metaheuristic.c:372) -- tour[-1] reads 0, tour[n]
+    reads 0 unless n % 4 == 2, where it reads the size field of the next heap chunk, which no draw matches -- settled
+    against the COMPILED REFERENCE run in a process of its own at n = 52 ... 85 902 (oracle/ref_kick_probe.c,
+    oracle/make_golden_kick_oob.py): 25 kicks after srand(77) on the fixture's cycle leave the same tour in the
+    reference, in the oracle and in the host layer; and the fixture records what the reference found at the two
+    addresses (never an mmapped block: glibc's dynamic threshold has moved past 4n by the first kick)"""
+    import numpy as np
+    n = case["n"]
+    succ = kick_oob_cycle(n)
+    assert f"{O.fnv1a(succ):016x}" == case["fnv_before"]
+    want = succ.copy()
+    O.libc_srand(KICK_OOB["seed"])
+    for _ in range(KICK_OOB["kicks"]):
+        O.vns_kick(want)
+    assert f"{O.fnv1a(want):016x}" == case["fnv"]                    # oracle == compiled reference
+    host.tsp_init()
+    host.err_setverbosity(0)
+    Instance.in_dll(host, "tsp_inst").nnodes = n
+    got = succ.copy()
+    host.tsp_srand.argtypes = [C.c_uint]
+    host.tsp_srand(KICK_OOB["seed"])
+    host.vns_kick.argtypes = [C.POINTER(Solution)]
+    sol = Solution(0.0, got.ctypes.data_as(C.POINTER(C.c_int)), 0, None)
+    for _ in range(KICK_OOB["kicks"]):
+        assert host.vns_kick(C.byref(sol)) == 0
+    assert f"{O.fnv1a(got):016x}" == case["fnv"]                     # host layer == compiled reference
+    # what the reference's process found at the two addresses: the model's premises
+    assert case["before_values"] == [0] and not case["any_mmapped"]
+    if n % 4 == 2:
+        assert case["after_min"] > 0                                 # a chunk size field (odd: PREV_INUSE), never calloc padding
+    else:
+        assert (case["after_min"], case["after_max"]) == (0, 0)
 
 
 # ------------------------------------------------------------------ the reference's signatures, one by one (VERDICT r2 "weak" 1)
@@ -581,3 +663,32 @@ def test_binary_walks_at_resident_sizes_against_the_compiled_reference():
         rc, out, err = run_q("-f", os.path.join(DATA, r["instance"] + ".tsp"), "-alg", alg, "-k", str(r["k"]))
         assert rc == 0, (key, err[-500:])
         assert out == "Cost: %.2f" % r["cost"], (key, out)
+
+
+@pytest.mark.gpu
+def test_mh_vns_stops_on_a_code_8_that_is_not_a_refill():
+    """tspgpu_vns_search answers RESOURCE_EXHAUSTED (8) both for "the random numbers ran out, call again"
+    and for real failures (here: the LDS-resident loop forced, TSPGPU_OPT_PERSIST = 2, on an instance it does not take --
+    n = 52 < 64).  mh_VNS must end with the reference's fatal exit (log_fatal + tsp_handlefatal, exit status 1), not
+    call again for ever.  Run in a child process: the fatal path exits."""
+    code = f"""
+import ctypes as C, os, sys
+host = C.CDLL({os.path.join(HOST, "libtsphost.so")!r})
+argv = [b"tsp", b"-f", {os.path.join(DATA, "berlin52.tsp")!r}.encode(), b"-alg", b"VNS", b"-k", b"50"]
+arr = (C.c_char_p * len(argv))(*argv)
+assert host.tsp_parse_commandline(len(argv), arr) == 0
+host.tsp_read_input()
+host.tsp_gpu.restype = C.c_void_p
+g = host.tsp_gpu()
+gpu = C.CDLL({os.path.join(ROOT, "travellingsalesmanoptimization_amd", "csrc", "libtspgpu.so")!r})
+gpu.tspgpu_set_option.argtypes = [C.c_void_p, C.c_int, C.c_long]
+sys.path.insert(0, {ROOT!r})
+from travellingsalesmanoptimization_amd import _lib
+assert gpu.tspgpu_set_option(g, _lib.OPT_PERSIST, 2) == 0
+os.makedirs("results", exist_ok=True)
+rc = host.tsp_run_algorithm()
+print("returned", rc)
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode == 1 and "returned" not in r.stdout, (r.returncode, r.stdout, r.stderr)
+    assert "Error in local search" in r.stderr and "does not apply" in r.stderr, r.stderr

@@ -573,7 +573,12 @@ ERROR_CODE mh_VNS(void)
             const double best0 = best.cost;
             const int rc = tspgpu_vns_search(g, s.path, &s.cost, upto, time_left(), rv, want, &used, &it, &pending, best.path, &best.cost, trace);
             tsp_rand_consume(used);
-            if (rc != 0 && rc != DEADLINE_EXCEEDED && rc != RESOURCE_EXHAUSTED) {
+            /* RESOURCE_EXHAUSTED means "the numbers ran out in front of a kick phase: come back with more" only when the call
+             * got somewhere (iterations done or numbers consumed: `want` covers far more than one kick phase).  The same code
+             * with no progress is a real failure (the resident loop forced where it does not apply, a plan that does not
+             * fit) and calling again would spin for ever */
+            const int refill = rc == RESOURCE_EXHAUSTED && (it > it0 || used > 0);
+            if (rc != 0 && rc != DEADLINE_EXCEEDED && !refill) {
                 log_fatal("code %d : Error in local search: %s", rc, tspgpu_last_error(g));
                 tsp_handlefatal();
             }
