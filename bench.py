@@ -244,6 +244,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--cpu-sweeps", type=int, default=300, help="bounded CPU baseline sample (0 = skip)")
     ap.add_argument("--batch-starts", type=int, default=64, help="starts of the batched multi-start leg (0 = skip)")
+    ap.add_argument("--job-starts", type=int, default=None, help="starts of the fixed-size sharded multi-start job timed at EVERY --gpus N (0 = skip)")
     ap.add_argument("--no-other", action="store_true", help="skip the comparison run with the other matrix storage")
     ap.add_argument("--no-sizes", action="store_true", help="skip the n=1024 / n=16384 rows of the throughput table")
     ap.add_argument("--no-otf", action="store_true", help="skip the matrix-free (pla85900) leg")
@@ -255,6 +256,8 @@ def main():
         args.no_other = args.no_sizes = args.no_otf = args.no_cpu_multistart = args.no_host_c = True
         args.cpu_sweeps = 0
         args.batch_starts = 0
+    if args.job_starts is None:
+        args.job_starts = 0 if args.lean else 512
 
     draw_points([(args.n, args.seed), (1024, 1), (16384, 123), (1024, 123), (3584, 123), (4096, 123)])
     global _VNS_RAND
@@ -335,17 +338,16 @@ def main():
                "kernel_evals_per_s": evals / (kernel_ms * 1e-3)}
         if info.get("persist"):
             # One launch runs the whole descent; the unit of work is one SWEEP (= the work of one launch of the per-sweep
-            # kernels: n(n-3)/2 evaluations, 2 matrix cells each).  The cells come from LDS, not HBM (PMC: ~1.2 MB of HBM
-            # traffic per sweep against 33.5 MB of algorithmic bytes), so this is NOT an HBM-bound kernel: what bounds a
-            # sweep is one grid-wide exchange (a fabric round trip all 256 workgroups wait for).  bound = "latency":
-            # achieved = us per sweep, peak = the measured floor of one exchange (tools/probes/slot_barrier_probe.hip),
-            # frac = floor / achieved.  SURVEY 8(d)'s convention (algorithmic bytes / time / 8 TB/s) is kept beside it as
-            # frac_nominal_hbm -- it can exceed what HBM could deliver and says nothing about HBM utilisation.
+            # kernels: n(n-3)/2 evaluations, 2 matrix cells each).  `frac` keeps SURVEY 8(d)'s convention -- algorithmic
+            # bytes / time / 8 TB/s -- although the cells come from LDS, not HBM (PMC: ~1.2 MB of HBM
+            # traffic per sweep against 33.5 MB of algorithmic bytes): what limits a sweep is one grid-wide exchange, named
+            # in `limited_by`; the ratio against the measured floor of one exchange is the secondary `exchange_floor_frac`.
             us = kernel_ms * 1e3
             ph = guarded(phase_clocks, eng)
-            out.update({"bound": "latency", "achieved": us, "peak": EXCHANGE_FLOOR_US, "unit": "us per sweep (lower is better)",
-                        "frac": EXCHANGE_FLOOR_US / us,
-                        "exchange_floor_us": EXCHANGE_FLOOR_US,
+            out.update({"limited_by": "latency: one grid-wide exchange per sweep (a fabric round trip all 256 workgroups wait for) + the "
+                                      "workgroups whose move phase reloads rows; the cells are read from LDS, not HBM",
+                        "us_per_sweep": us,
+                        "exchange_floor_us": EXCHANGE_FLOOR_US, "exchange_floor_frac": EXCHANGE_FLOOR_US / us,
                         "exchange_floor_source": "profiles/r03_xcd_exchange_probe.txt (256 workgroups, 16-byte records at 64-byte stride, flat: 2.0-2.2 us; "
                                                  "the two-level form through the XCDs' L2s measures the same)",
                         "phase_us": ph,
@@ -382,6 +384,33 @@ def main():
         got = {"sweeps": int(sweeps), "final_cost": float(cost), "final_fnv": fnv1a(path)}
         ok = all(got[k] == g[k] for k in got)
         return {"golden": f"tests/golden: n{n}_s{seed} two_opt (compiled reference)", "ok": ok, **got}
+
+    def multistart_golden():
+        """per-start results of h_greedy_2opt's loop on -n 4096 -seed 123 from the compiled reference"""
+        try:
+            g = json.load(open(os.path.join(GOLDEN, "golden_n4096_multistart.json")))
+            return {e["start"]: e for e in g["starts"]} if (g["n"], g["seed"]) == (n, seed) else None
+        except OSError:
+            return None
+
+    def multistart_gate(e, starts, res, check_slots=8):
+        """a batched multi-start against the compiled reference's per-start goldens: winner (cost, start, tour hash), sweep
+        total, and the first `check_slots` starts' own final cost and tour read back from their slots"""
+        g = multistart_golden()
+        if g is None or any(int(st) not in g for st in starts):
+            return {"golden": None}
+        want = [g[int(st)] for st in starts]
+        best = min(want, key=lambda w: (w["cost"], w["start"]))
+        got = {"best_cost": float(res["cost"]), "best_start": int(res["start"]), "best_fnv": fnv1a(res["path"]), "sweeps": int(res["sweeps"])}
+        ok = got == {"best_cost": best["cost"], "best_start": best["start"], "best_fnv": best["fnv"], "sweeps": sum(w["sweeps"] for w in want)}
+        slots_ok = 0
+        for slot in range(min(check_slots, len(want))):
+            p_, c_, _ = e.tour_store(slot)
+            good = (float(c_), fnv1a(p_)) == (want[slot]["cost"], want[slot]["fnv"])
+            slots_ok += good
+            ok = ok and good
+        return {"golden": f"tests/golden/golden_n4096_multistart.json ({len(want)} starts, compiled reference)", "ok": bool(ok),
+                "per_start_checked": int(min(check_slots, len(want))), "per_start_ok": int(slots_ok), **got}
 
     def search_row(n, seed, steps, warmup, elem, cpu_sweeps, port):
         """one row of the throughput table on its own engine (single GPU)"""
@@ -482,6 +511,57 @@ def main():
     if gate and gate.get("golden") and not gate["ok"]:
         raise SystemExit(f"parity gate failed: {gate}")        # a fast kernel whose result differs is not a result
 
+    # ---- north_star's multi-GPU criterion: ONE fixed job -- h_greedy_2opt's loop (heuristics.c:74-116)
+    # over the first `job_starts` start nodes of this instance -- sharded p mod N over the ranks (multistart.py), every rank's
+    # shard one batched call of the HIP engine, ONE MIN all-reduce + ONE broadcast (RCCL) to select the winner.  Timed at
+    # every N including 1, so the driver's N = 1, 2, 4, 8 runs give the strong-scaling curve of the same job.
+    job = None
+    if args.job_starts > 0:
+        jstarts = np.arange(min(args.job_starts, n), dtype=np.int32)
+
+        def solve_local(mine):
+            r_ = eng.multistart_nn_2opt(mine)
+            solve_local.mine, solve_local.res = mine, r_
+            return r_
+
+        def job_leg():
+            eng.multistart_nn_2opt(jstarts[rank::world][:4])           # warm-up: plan, slots, graphs
+            sync_all()
+            t1 = time.perf_counter()
+            res_j = multistart.multistart_nn_2opt(solve_local, jstarts, device=dev, n=n)
+            sync_all()
+            dtj = time.perf_counter() - t1
+            # every rank checks its own shard against the compiled reference's per-start goldens
+            gl = multistart_gate(eng, solve_local.mine, solve_local.res)
+            ok_l = 1 if (gl.get("golden") is None or gl["ok"]) else 0
+            if world > 1:
+                tj = torch.tensor([dtj], dtype=torch.float64, device=dev)
+                dist.all_reduce(tj, op=dist.ReduceOp.MAX)
+                okt = torch.tensor([ok_l], dtype=torch.int64, device=dev)
+                dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+                dtj, ok_l = float(tj.item()), int(okt.item())
+            g = multistart_golden()
+            whole = None
+            if g is not None and all(int(st) in g for st in jstarts):
+                want = [g[int(st)] for st in jstarts]
+                best = min(want, key=lambda w: (w["cost"], w["start"]))
+                whole = (float(res_j["cost"]), int(res_j["start"]), fnv1a(res_j["path"]), int(res_j["sweeps"])) == \
+                        (best["cost"], best["start"], best["fnv"], sum(w["sweeps"] for w in want))
+            out_j = {"what": f"All-NN + 2OPT (h_greedy_2opt, heuristics.c:74-116) over starts 0..{len(jstarts) - 1} of the n={n} instance: a FIXED job, "
+                             "start p -> rank p mod N, one batched engine call per rank, one MIN all-reduce of the packed (cost, start, rank) key + "
+                             "one broadcast of the winner's tour",
+                     "scaling": "strong", "starts": int(len(jstarts)), "ranks": world, "backend": backend or "none (single rank: no exchange)",
+                     "seconds": dtj, "sweeps": int(res_j["sweeps"]), "value": res_j["sweeps"] * evals / dtj, "unit": "evals/s",
+                     "best_cost": float(res_j["cost"]), "best_start": int(res_j["start"]),
+                     "tours_in_flight_per_rank": int(len(jstarts[rank::world])),
+                     "parity": {"golden": gl.get("golden"), "every_rank_shard_ok": bool(ok_l) if gl.get("golden") else None,
+                                "whole_job_ok": whole, "rank0_shard": gl}}
+            if gl.get("golden") and (not ok_l or whole is False):
+                raise SystemExit(f"parity gate of the sharded multi-start job failed: {out_j['parity']}")
+            return out_j
+        job = job_leg()      # not guarded: every rank takes part in its collectives, and a wrong result must fail the run
+        eng.tour_nn(0, start)        # (the job used the slots: the legs below expect the NN tour in slot 0 again)
+
     roof = roof_fused = None
     if rank == 0:
         roof = timed_search(eng, evals)
@@ -543,12 +623,31 @@ def main():
             t1 = time.perf_counter()
             res = eng.multistart_nn_2opt(starts)
             dtb = time.perf_counter() - t1
-            bpe = 2 * BYTES[eng.info()["elem"]]
+            info_b = eng.info()
+            gate_b = multistart_gate(eng, starts, res)
+            if gate_b.get("golden") and not gate_b["ok"]:
+                raise SystemExit(f"parity gate of the batched multi-start failed: {gate_b}")
+            bpe = 2 * BYTES[info_b["elem"]]
+            # the same call once more with HIP events around every sweep launch of the batch (graphs off): the dominant kernel's
+            # own time.  One launch sweeps every live tour of the batch: its algorithmic bytes = live tours x evals x bpe
+            eng.set_option(T.OPT_TIMING, 1); eng.timing_read(reset=True)
+            res_t = eng.multistart_nn_2opt(starts)
+            ms_total, launches = eng.timing_read(reset=True)
+            eng.set_option(T.OPT_TIMING, 0)
+            ach = res_t["sweeps"] * evals * bpe / (ms_total * 1e-3) / 1e9
             return {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
-                    "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"],
+                    "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"], "best_start": int(res["start"]),
+                    "parity": gate_b,
                     "includes": "NN construction + 2-opt of every start, host arrays in/out",
-                    # SURVEY 8(d)'s convention for the streamed kernels: 2 matrix cells per evaluation / time / the HBM peak.  The
-                    # tours of a batch share one matrix, so part of these bytes are last-level-cache hits: a nominal fraction
+                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                                 "traffic": None, "traffic_from_committed_profile": load_traffic(f"n{n}_{NAMES[info_b['elem']]}_batch{args.batch_starts}"),
+                                 "kernel": "k_sweep_pipe (rows streamed, runs of n/64 edges; one launch sweeps every live tour of the batch)",
+                                 "kernel_ms_mean": ms_total / max(launches, 1), "kernel_launches_timed": int(launches),
+                                 "algorithmic_bytes_per_launch": res_t["sweeps"] * evals * bpe / max(launches, 1),
+                                 "mean_live_tours_per_launch": res_t["sweeps"] / max(launches, 1), "bytes_per_eval": bpe,
+                                 "note": "HIP events around every sweep launch of a second, identical call (k_apply and NN are outside); the "
+                                         "tours of a batch share one 33.5 MB matrix, so part of these bytes are last-level-cache hits"},
+                    # SURVEY 8(d)'s convention over the whole call (NN + sweeps + applies, host in/out)
                     "nominal_hbm": {"bytes_per_eval": bpe, "achieved_GBs": res["sweeps"] * evals * bpe / dtb / 1e9,
                                     "peak_GBs": HBM_PEAK_GBS, "frac": res["sweeps"] * evals * bpe / dtb / 1e9 / HBM_PEAK_GBS,
                                     "kernel": "k_sweep_pipe (rows streamed, runs of n/64 edges)"}}
@@ -576,6 +675,13 @@ def main():
                 _, c_nn, _ = e3.tour_store(0, want_path=False)
                 nn_s = time.perf_counter() - t1
                 ms = e3.time_sweep(0, 5)
+                # NN(0) -> 2-opt LOCAL OPTIMUM on the matrix-free engine (BASELINE config 5's local search, refinment.c:3-37;
+                # tests/test_gpu_parity.py::test_pla85900_config5_local_optimum_and_vns certifies this tour with an oracle sweep)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                sw3, rc3 = e3.tour_two_opt(0)
+                desc_s = time.perf_counter() - t1
+                _, c_opt, _ = e3.tour_store(0, want_path=False)
             finally:
                 e3.close()
             m = len(pts)
@@ -584,6 +690,9 @@ def main():
             return {"workload": f"pla85900 ({ewt}, n={m}), matrix-free: no n x n array (59 GB of doubles in the reference's format)",
                     "matrix_free": info["matrix_free"], "ms_per_sweep": ms, "evals_per_sweep": ev, "value": ev / (ms * 1e-3),
                     "unit": "evals/s", "nn_tour_s": nn_s, "nn_cost": c_nn,
+                    "descent": {"what": "NN(0) -> 2-opt local optimum, all in (one call, host polls included)", "sweeps": int(sw3), "rc": int(rc3),
+                                "seconds": desc_s, "evals_per_s": sw3 * ev / desc_s, "ms_per_sweep_all_in": 1e3 * desc_s / max(sw3, 1),
+                                "final_cost": c_opt},
                     "roofline": {"bound": "valu", "achieved": ev / (ms * 1e-3), "peak": ceil["ceiling_evals_per_s"], "unit": "evals/s",
                                  "frac": ev / (ms * 1e-3) / ceil["ceiling_evals_per_s"], "traffic": None,
                                  "kernel": ceil["kernel"], "issue_cycles_per_pair": ceil["issue_cycles_per_pair"],
@@ -778,7 +887,7 @@ def main():
         "final_cost_rank0": final_cost, "nn_cost_rank0": nn_cost, "parity": gate,
         "matrix_build_ms": broof["kernel_ms_mean"], "nn_tour_ms": nn_ms,
         "roofline": roof, "roofline_one_launch_per_sweep": roof_fused, "roofline_build": broof, "cpu_baseline": base,
-        "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
+        "other_matrix_storage": other, "sizes": sizes, "multistart_batch": batch, "multistart_job": job, "otf": otf, "cpu_multistart_baseline": cpu_ms, "host_c_path": host_c,
         "tabu_walk": tabu, "vns_walk": vns, "config2_fnl4461": cfg2,
     }
     if base and "value" in base:
