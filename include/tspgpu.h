@@ -77,6 +77,11 @@ enum {
     TSPGPU_OPT_BUILD_KERNEL = 19,  /* tspgpu_build_costs with uint16 cells: 0 (default) the upper triangle computed once, every
                                    64 x 64 tile stored twice (as it is and transposed through LDS), 1 every cell computed
                                    (what int32 / f64 cells always do) */
+    TSPGPU_OPT_STREAM_PERSIST = 20,/* single-tour descent past the LDS-resident sizes (uint16 cells, n from about 5400 to 16383)
+                                   in ONE launch with the rows streamed and the tour state kept on the chip (k_str2opt, one
+                                   workgroup per CU, one grid-wide exchange per sweep): 0 never, 1 (default) where it applies
+                                   -- falls back to one launch per sweep when the grid cannot be co-resident --, 2 or fail with
+                                   code 8 (and used from n = 1024 up) */
     TSPGPU_OPT_PERSIST_WINDOW = 18 /* rows of that kernel: 0 auto (whole rows where they fit the chip's LDS, else the half
                                    window of n/2 cells ahead of the workgroup's own edges), 1 half-window rows wherever they
                                    apply, 2 whole rows only */
@@ -97,7 +102,8 @@ int  tspgpu_set_option(tspgpu_ctx *ctx, int option, long value);
  * row of its half-window form (0: whole rows), 20 the last single-tour descent ran in the half-window form, 21 the last
  * single-tour descent began LDS-resident and was finished one launch per sweep (the grid lost its co-residency), 22 sweeps run by the last
  * LDS-resident descent / tabu walk / VNS walk, 23 how the last tspgpu_vns_search ran (1 resident throughout, 2 one device local
- * search per iteration with the kicks on the host, 3 resident launches first, then -- the grid lost its co-residency -- host kicks) */
+ * search per iteration with the kicks on the host, 3 resident launches first, then -- the grid lost its co-residency -- host kicks),
+ * 24 the last single-tour descent ran in the streamed persistent kernel (TSPGPU_OPT_STREAM_PERSIST) */
 long tspgpu_info(const tspgpu_ctx *ctx, int what);
 
 /* ---- instance / cost matrix ------------------------------------------- */

@@ -1506,6 +1506,73 @@ def test_lds_window_falls_back_past_its_limit(eng, T, O):
         eng.set_option(T.OPT_PERSIST, 1)
 
 
+# ------------------------------------------------------------------ the streamed persistent descent (k_str2opt)
+@pytest.fixture
+def stream(eng, T):
+    """TSPGPU_OPT_STREAM_PERSIST = 2: the single-tour descent must run in k_str2opt (or fail loudly); the LDS-resident
+    kernels are switched off so that it is reached at every size"""
+    eng.set_option(T.OPT_PERSIST, 0); eng.set_option(T.OPT_STREAM_PERSIST, 2)
+    yield
+    eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_STREAM_PERSIST, 1)
+
+
+@pytest.mark.parametrize("name", ["pr1002", "n1024_s1", "n4096_s123"])
+def test_stream_persist_to_local_optimum_golden(eng, T, O, instances, golden, name, stream):
+    """the whole descent in ONE launch with streamed rows and the tour state on the chip (k_str2opt): golden sweep count,
+    final cost, tour and every recorded move against the oracle"""
+    if name == "pr1002":
+        pytest.skip("n = 1002 < 1024: below the kernel's range")
+    xy, c = setup(eng, T, O, instances, name, 3, 0)
+    g = (golden["instances"].get(name) or golden["random"][name])["two_opt"]
+    succ, nn_cost = O.nn_tour(c, 0)
+    sw = _descent_against_oracle(eng, O, c, succ, nn_cost, -1)
+    assert eng.info()["stream_persist"] == 1 and eng.info()["persist"] == 0
+    got, gcost, _ = eng.tour_store(0)
+    assert (sw, gcost, fx(O, got)) == (g["sweeps"], g["final_cost"], g["final_fnv"])
+
+
+@pytest.mark.parametrize("n", [1024, 1025, 1500, 2047, 3000, 4097, 5600, 6144, 7000, 8191, 8192])
+def test_stream_persist_size_sweep(eng, T, O, n, stream):
+    """sizes around the kernel's geometry (odd n, ld > n, the last workgroup short, one chunk per thread full): 40 sweeps in
+    one launch against the oracle, move by move -- from a start in the middle so that long reversals, both directions and
+    wrapping ranges occur"""
+    xy = O.random_points(n, 3000 + n)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, n // 3)
+    sw = _descent_against_oracle(eng, O, c, succ, cost, 40)
+    assert sw <= 40 and eng.info()["stream_persist"] == 1
+
+
+def test_stream_persist_is_the_default_past_the_lds_sizes(eng, T, O):
+    """n = 5800 (past the half-window kernel): the default single-tour descent runs in k_str2opt, says so, and agrees with
+    the oracle; sweep cap and a deadline leave one consistent state"""
+    n = 5800
+    xy = O.random_points(n, 7)
+    c = O.cost_matrix(xy)
+    eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_STREAM_PERSIST, 1)
+    eng.set_points(xy); eng.build_costs()
+    succ, cost = O.nn_tour(c, 0)
+    sw = _descent_against_oracle(eng, O, c, succ, cost, 25)
+    info = eng.info()
+    assert sw == 25 and info["stream_persist"] == 1 and info["persist"] == 0
+    # under a deadline: code 4, the tour / cost / sweep count / history are ONE state
+    eng.set_option(T.OPT_HISTORY, 4096)
+    try:
+        g = succ.copy()
+        gcost, sweeps, rc = eng.two_opt(g, time_left_s=0.002)
+        a, b, d = eng.history(4096)
+        assert rc == 4 and 0 < sweeps < 700 and len(a) == sweeps
+        o, ocost = succ.copy(), cost
+        for i in range(sweeps):
+            dd, ocost, mv = O.two_opt_once(c, o, ocost)
+            assert (int(a[i]), int(b[i]), float(d[i])) == (mv[0], mv[1], dd)
+        assert gcost == ocost and np.array_equal(g, o)
+    finally:
+        eng.set_option(T.OPT_HISTORY, 0)
+
+
 def test_lds_resident_hands_over_mid_descent(T, O, instances, golden):
     """a deadline-bounded descent relaunches k_lds2opt per sweep budget; when a LATER launch no longer gets
     the whole chip (test hook 96 makes the 2nd launch fail its rendezvous, as another context holding CUs would) the rest

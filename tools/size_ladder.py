@@ -17,7 +17,8 @@ for n in sizes:
         eng.tour_copy(1, 0); eng.tour_store(1, want_path=False)
         t0 = time.perf_counter(); sw, rc = eng.tour_two_opt(1); ts.append(time.perf_counter() - t0)
     i = eng.info()
-    kern = ("k_lds2opt_w (half windows)" if i["persist_window"] else "k_lds2opt (whole rows)") if i["persist"] else \
+    kern = "k_str2opt (streamed, one launch)" if i.get("stream_persist") else \
+           ("k_lds2opt_w (half windows)" if i["persist_window"] else "k_lds2opt (whole rows)") if i["persist"] else \
            ("k_sweep_fused" if i["fused"] else "k_sweep_*") + f" block {i['block']} x {i['wgs_per_tour']} wgs"
     best = min(ts[1:])
     print(f"n={n:6d} elem={['','f64','i32','u16'][i['elem']]} {kern:38s} sweeps={sw:5d} {best*1e3:9.3f} ms = {best/sw*1e6:7.2f} us/sweep  "

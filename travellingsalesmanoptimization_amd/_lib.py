@@ -20,7 +20,7 @@ EUC_2D, ATT, CEIL_2D = 0, 1, 2
 ELEM_AUTO, ELEM_F64, ELEM_I32, ELEM_U16 = 0, 1, 2, 3
 OPT_ELEM, OPT_KERNEL, OPT_BATCH, OPT_WGS_PER_TOUR, OPT_HISTORY = 1, 2, 3, 4, 5
 OPT_GRAPH, OPT_TIMING, OPT_BLOCK, OPT_MAX_TOURS, OPT_DEPTH, OPT_MATRIX_FREE, OPT_FUSED, OPT_SWEEP_CAP, OPT_NN_KERNEL, OPT_PIPE2 = 6, 7, 8, 9, 10, 11, 12, 13, 14, 15
-OPT_PERSIST, OPT_PERSIST_EDGES, OPT_PERSIST_WINDOW, OPT_BUILD_KERNEL = 16, 17, 18, 19
+OPT_PERSIST, OPT_PERSIST_EDGES, OPT_PERSIST_WINDOW, OPT_BUILD_KERNEL, OPT_STREAM_PERSIST = 16, 17, 18, 19, 20
 MOPT_EXCHANGE = 1000
 EXCHANGE_AUTO, EXCHANGE_HOST, EXCHANGE_RCCL = 0, 1, 2
 

@@ -1640,6 +1640,84 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
 #undef STAMP
 }
 
+// Two steps of an interval at once (uint16 cells, symmetric matrix, plain 2-opt): a wave that owns pairs of BOTH tour edges
+// of a barrier interval evaluates them as ONE instruction stream -- sixteen gathers in flight, two independent arithmetic
+// chains -- instead of one step after the other.  Why: a sweep over streamed rows is bound by the dependent chain of a
+// wave-step (three LDS round trips, ~60 dependent vector instructions: 0.3 us) with one or two active waves per SIMD, and an
+// interval ends with its slowest wave, which is the one that owns pairs of both edges (tools/stream_probe.py: 0.6 us per step
+// whatever the rows in flight).  Returns false when a chunk needs the masked variant (a's own block, a pad wave): the
+// caller then takes the two steps one after the other through sweep_step_as.
+template <int NCH>
+__device__ __forceinline__ bool sweep_step_dual(Best &q, const BState<u16, NCH> &B, const unsigned char *bS1, unsigned ldsS1, int a1, int sa1,
+                                                const v8u16 *areg1, const unsigned char *bS2, unsigned ldsS2, int a2, int sa2,
+                                                const v8u16 *areg2, int n, int BT, int tid, int wave_base)
+{
+    constexpr int V = 8;
+    const int NB = (n + 64 * V - 1) / (64 * V);
+    const int blk1 = a1 / (64 * V), blk2 = a2 / (64 * V);
+    int st1[NCH], st2[NCH];                           // per chunk: 0 not this orientation's, 1 evaluate (no mask needed)
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        const int w0 = (c * BT + wave_base) * V;
+        st1[c] = st2[c] = 0;
+        if (w0 >= n) continue;
+        if (w0 + 64 * V > n) return false;            // pad lanes: masked variant
+        const int blkb = w0 / (64 * V);
+        int d1 = blkb - blk1, d2 = blkb - blk2;
+        if (d1 < 0) d1 += NB;
+        if (d2 < 0) d2 += NB;
+        if (d1 == 0 || d2 == 0) return false;         // a's own block: masked variant
+        st1[c] = (2 * d1 < NB || (2 * d1 == NB && blk1 < blkb)) ? 1 : 0;
+        st2[c] = (2 * d2 < NB || (2 * d2 == NB && blk2 < blkb)) ? 1 : 0;
+    }
+    const int da1 = (int)reinterpret_cast<const u16 *>(bS1)[a1], da2 = (int)reinterpret_cast<const u16 *>(bS2)[a2];   // c[a][succ a] = c[succ a][a]
+    auto gather = [&](int (&g)[V], unsigned ldsS, int c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            unsigned addr;
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
+                : "=v"(addr) : "v"(ldsS), "v"(B.sb[c][v]));
+            g[v] = (int)*(const lds_u16 *)(uintptr_t)addr;
+        }
+    };
+    auto chain = [&](const int (&g)[V], const v8u16 &xa, int c, int a, int d_a) __attribute__((always_inline)) {
+        int m = 0x7fffffff;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            int dl;
+            const int made = (int)xa[v] + g[v];
+            asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
+                : "=v"(dl) : "v"(made), "v"(B.sb[c][v]));
+            m = min(m, (dl << 3) | v);
+        }
+        const int b = (c * BT + tid) * V + (m & 7);
+        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
+        return (long long)(((u64)(unsigned)((m >> 3) - d_a) << 32) | lohi);
+    };
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+        if (st1[c] && st2[c]) {
+            int g1[V], g2[V];
+            gather(g1, ldsS1, c);
+            gather(g2, ldsS2, c);
+            const long long k1 = chain(g1, areg1[c], c, a1, da1), k2 = chain(g2, areg2[c], c, a2, da2);
+            const long long k = k1 < k2 ? k1 : k2;
+            q.k = k < q.k ? k : q.k;
+        } else if (st1[c]) {
+            int g1[V];
+            gather(g1, ldsS1, c);
+            const long long k = chain(g1, areg1[c], c, a1, da1);
+            q.k = k < q.k ? k : q.k;
+        } else if (st2[c]) {
+            int g2[V];
+            gather(g2, ldsS2, c);
+            const long long k = chain(g2, areg2[c], c, a2, da2);
+            q.k = k < q.k ? k : q.k;
+        }
+    }
+    return true;
+}
+
 // Streaming, second form (symmetric matrices, plain 2-opt, rows that fit LDS FOUR times): TWO tour edges per barrier
 // interval, and the row of a straight from the registers that loaded it.  In pipe_stream() a thread writes the vector
 // it fetched into LDS and reads the very same bytes back one step later as c[a][own b's] -- only the row of succ a
@@ -1653,7 +1731,7 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
 // that owns no pair of one step usually owns pairs of the other (ownership goes by block distance from a, and a and
 // succ a sit in different blocks): the 16 waves of a workgroup idle at the barrier far less.  c[a][succ a] is read as
 // c[succ a][a] from the gather row (symmetric), so the row of a is never needed in LDS.
-template <typename T, int NCH, int PAIRS>
+template <typename T, int NCH, int PAIRS, bool DUAL = false>
 __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
                                              int cnt, unsigned long long *stamp)
 {
@@ -1701,8 +1779,22 @@ __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const 
     // interval gathered from; registers rotate; the pair is re-issued for the rows four intervals' worth ahead
     auto interval = [&](int s, VT(&P0)[NCH], VT(&P1)[NCH], auto tail_tag) __attribute__((always_inline)) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        step(s, A0);
-        if (!TAIL || s + 1 < cnt) step(s + 1, A1);
+        bool both = false;
+        if constexpr (DUAL && sizeof(T) == 2) {
+            if ((!TAIL || s + 1 < cnt) && A.ablate != 1) {
+                const int a1 = __builtin_amdgcn_readfirstlane(nodes[s]), a2 = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
+                const int a3 = __builtin_amdgcn_readfirstlane(nodes[s + 2]);
+                const int sl1 = (s + 1) & 3, sl2 = (s + 2) & 3;
+                both = sweep_step_dual<NCH>(q, B, reinterpret_cast<const unsigned char *>(buf + (size_t)sl1 * ld),
+                                            lds0 + (unsigned)(sl1 * ld) * 2u, a1, a2, A0,
+                                            reinterpret_cast<const unsigned char *>(buf + (size_t)sl2 * ld),
+                                            lds0 + (unsigned)(sl2 * ld) * 2u, a2, a3, A1, n, BT, tid, wave_base);
+            }
+        }
+        if (!both) {
+            step(s, A0);
+            if (!TAIL || s + 1 < cnt) step(s + 1, A1);
+        }
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         if (!TAIL || s + 3 <= cnt) land(P0, s + 3);
         if (!TAIL || s + 4 <= cnt) land(P1, s + 4);
@@ -2930,6 +3022,7 @@ __global__ void k_cap_now(Tours S, int slot0, int count)
 
 #include "tspgpu_lds2opt.inc"
 #include "tspgpu_lds2opt_win.inc"
+#include "tspgpu_str2opt.inc"
 
 // ===========================================================================
 // host side
@@ -3018,6 +3111,11 @@ struct tspgpu_ctx {
     int lp_skip = 0, lp_backoff = 16;   // the grid did not come up co-resident: the next lp_skip descents keep to the one-launch-per-sweep
                                         // path, then it is tried again (16, 32, ... 1024 descents apart while it keeps failing)
     bool lp_used = false;      // the last descent ran in k_lds2opt
+    // streamed persistent descent (k_str2opt): single tours past the LDS-resident sizes, uint16 cells
+    int opt_stream = 1;        // 0 never, 1 where it applies (uint16 cells, one tour, n past k_lds2opt_w, a whole idle chip), 2 or fail
+    bool sp_used = false;      // the last descent ran in k_str2opt
+    bool sp_attr[4] = {false, false, false, false};
+    int opt_sp_nch = 0;        // probe hook 93
     bool lp_attr[6] = {false, false, false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
     bool max8k = false;        // ... <= 8190 (the tabu form of the packed loop: a poisoned pair must exceed every valid delta)
@@ -3999,6 +4097,122 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
     return E_OK;
 }
 
+// The streamed persistent descent (k_str2opt) where it applies: uint16 cells, one tour, a symmetric matrix too large for the
+// LDS-resident kernels, four rows + the node-per-cell array in one workgroup's LDS, a whole idle chip.
+static bool stream_fits(const tspgpu_ctx *ctx, int &P, int &W, int &BT, int &NCH, size_t &lds)
+{
+    const int n = ctx->n, ld = ctx->ld;
+    if (ctx->elem != TSPGPU_ELEM_U16 || ctx->otf || !ctx->symmetric || !ctx->d_mat || n < 1024 || n >= 16384) return false;
+    const int cus = std::min(ctx->cus, 256);
+    P = (n + cus - 1) / cus;
+    W = (n + P - 1) / P;
+    NCH = ld / 8 <= 1024 ? 1 : 2;
+    if (ctx->opt_sp_nch > 0) NCH = ctx->opt_sp_nch;    // undocumented (option 93): force one / two 16-byte vectors per thread
+    BT = std::max(256, ((ld / 8 + NCH - 1) / NCH + 63) & ~63);     // (at least the 256 lanes that poll the exchange slots)
+    if (BT > 1024 || P < 2 || P > 64) return false;
+    lds = sp_lds_rows(ld) + sp_lds_ord(n) + sp_lds_nodes(P) + SP_LDS_SCRATCH;
+    lds = std::max<size_t>(lds, 84 * 1024);           // more than half a CU's LDS: one workgroup per CU, every CU one
+    return lds <= ctx->lds_max && W <= 256;
+}
+
+// *ran = false: nothing was touched (does not apply, or the grid did not come up co-resident).  Deadline: launches with a
+// sweep budget, as run_persist; every launch leaves a consistent tour in the slot.
+static int run_pstream(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *deadline_hit, bool *ran)
+{
+    *ran = false;
+    const double time_left_s = time_left_io ? *time_left_io : -1.0;
+    int P = 0, W = 0, BT = 0, NCH = 0;
+    size_t lds = 0;
+    if (!stream_fits(ctx, P, W, BT, NCH, lds)) return E_OK;
+    if (ctx->lp_skip > 0) { ctx->lp_skip--; return E_OK; }
+    if (!ctx->d_lp_slots) {
+        HIP_TRY(hipMalloc(&ctx->d_lp_slots, (size_t)2 * LP_BT * 64 + 64));
+        HIP_TRY(hipHostMalloc(&ctx->h_lp, 64));
+    }
+    // (the register budget follows the block: 768 threads leave 170 registers a thread, 512 leave 256)
+    const int vi = NCH == 1 ? (BT <= 768 ? 0 : 1) : (BT <= 512 ? 2 : 3);
+    const void *fn = vi == 0 ? (const void *)k_str2opt<1, 768> : vi == 1 ? (const void *)k_str2opt<1, 1024>
+                   : vi == 2 ? (const void *)k_str2opt<2, 512> : (const void *)k_str2opt<2, 1024>;
+    if (!ctx->sp_attr[vi]) {
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_max));
+        ctx->sp_attr[vi] = true;
+    }
+    const double t_end = time_left_s >= 0 ? now_s() + time_left_s : -1;
+    if (t_end >= 0 && time_left_s <= 0) { if (deadline_hit) *deadline_hit = true; *ran = true; ctx->sp_used = true; return E_OK; }
+    double sweep_s = 2e-9 * (double)ctx->n * ctx->n / 5.0e3 + 5e-6;     // first guess: the rows at 5 TB/s + the exchange
+    bool first = true, late = false;
+    int retries = 0;
+    ctx->lp_sweeps = 0;
+    auto hand_over = [&]() {
+        ctx->lp_handed = !first;
+        ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
+        if (time_left_io && t_end >= 0) *time_left_io = std::max(0.0, t_end - now_s());
+        return E_OK;
+    };
+    for (;;) {
+        int budget = -1;
+        if (t_end >= 0) {
+            const double left = t_end - now_s();
+            if (left <= 0) { late = true; break; }
+            budget = (int)std::min(1048576.0, std::max(1.0, left / 3.0 / sweep_s));
+        }
+        int *d_ctl = reinterpret_cast<int *>(ctx->d_lp_slots + (size_t)2 * W * 8);
+        HIP_TRY(hipMemsetAsync(ctx->d_lp_slots, 0, (size_t)2 * W * 64 + 64, ctx->stream));
+        StreamArgs A;
+        memset(&A, 0, sizeof A);
+        A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
+        A.P = P; A.budget = budget; A.poll_sleep = ctx->opt_lp_poll_sleep; A.prefetch = 0; A.ablate = ctx->opt_ablate;
+        A.slots = ctx->d_lp_slots; A.ctl = d_ctl; A.hist = ctx->hist;
+        A.hello_ticks = ctx->opt_lp_hello;
+        if (ctx->opt_lp_fail_at > 0 && !first) { ctx->opt_lp_fail_at--; A.hello_ticks = -5000; }
+        A.spin_ticks = 100000000;      // 1 s
+        A.stamps = ctx->opt_stamps ? ctx->d_stamps : nullptr;
+        void *args[] = {&A};
+        const double t0 = now_s();
+        if (ctx->opt_timing) {
+            while ((int)ctx->ev.size() < 2) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ev.push_back(e); }
+            HIP_TRY(hipEventRecord(ctx->ev[0], ctx->stream));
+        }
+        {
+            const hipError_t le = hipLaunchKernel(fn, dim3(W), dim3(BT), args, lds, ctx->stream);
+            if (le != hipSuccess) {
+                (void)hipGetLastError();
+                if (first) { ctx->lp_skip = 1 << 30; return E_OK; }
+                return fail(ctx, E_INTERNAL, "streamed persistent descent: launch failed: %s", hipGetErrorString(le));
+            }
+        }
+        if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
+        HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        const int status = ctx->h_lp[1], sd = ctx->h_lp[2];
+        if (status == LP_ST_NO_RENDEZVOUS) {
+            if (first) {
+                ctx->lp_skip = ctx->lp_backoff; ctx->lp_backoff = std::min(1024, ctx->lp_backoff * 2);
+                return E_OK;
+            }
+            if (++retries > 3) return hand_over();
+            continue;
+        }
+        if (status == LP_ST_LOST) return hand_over();  // an exchange timed out mid-launch: nothing of this launch was written
+        if (status == LP_ST_RUNNING)
+            return fail(ctx, E_INTERNAL, "streamed persistent descent: no status written (after %d sweeps)", sd);
+        first = false;
+        ctx->lp_backoff = 16;
+        ctx->lp_sweeps += sd;
+        if (ctx->opt_timing && sd > 0) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+            ctx->sweep_ms_total += ms; ctx->sweep_launches += sd;
+        }
+        if (sd > 0) sweep_s = (now_s() - t0) / sd;
+        if (status == LP_ST_OPTIMUM || status == LP_ST_CAPPED) break;
+    }
+    if (late && deadline_hit) *deadline_hit = true;
+    *ran = true;
+    ctx->sp_used = true;
+    return E_OK;
+}
+
 // Run (sweep, apply) pairs on slots [slot0, slot0+ntours) until every tour is
 // done, `max_iters` pairs were issued (tabu), or the deadline passed (checked before every batch; the batches
 // shrink to single iterations once fewer than three batches' worth of time is left, refinment.c:17-24).
@@ -4009,6 +4223,27 @@ __global__ void k_rebase(Tours S, int slot, int delta)     // sweep counter and 
 }
 
 static int run_sweeps_plain(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s, bool *deadline_hit);
+
+// A one-launch descent began and lost its grid (another context took CUs): the slot holds the tour its last completed
+// launch wrote back.  The per-sweep kernels count their sweeps from 0: run them on a rebased counter / cap / history and shift
+// everything back afterwards.
+static int run_rebased(tspgpu_ctx *ctx, int slot0, long max_iters, double time_left_s, bool *deadline_hit)
+{
+    int base = 0;
+    HIP_TRY(hipMemcpyAsync(&base, ctx->S.nsweeps + slot0, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const HistBuf keep = ctx->hist;
+    const int hb = std::min(base, keep.cap);
+    if (keep.cap > 0) { ctx->hist.a += hb; ctx->hist.b += hb; ctx->hist.d += hb; ctx->hist.cap -= hb; }
+    drop_graphs(ctx);
+    hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, -base);
+    int rc2 = run_sweeps_plain(ctx, slot0, 1, false, max_iters, time_left_s, deadline_hit);
+    hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, base);
+    if (!rc2 && hipGetLastError() != hipSuccess) rc2 = fail(ctx, E_INTERNAL, "k_rebase launch failed");
+    ctx->hist = keep;
+    drop_graphs(ctx);
+    return rc2;
+}
 
 static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s,
                       bool *deadline_hit)
@@ -4030,26 +4265,27 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
         const int rc = run_persist(ctx, slot0, &time_left_s, deadline_hit, &ran);     // (half way handed over: time_left_s = what is left)
         if (rc) return rc;
         if (ran) return E_OK;
-        if (ctx->lp_handed) {
-            // The LDS-resident kernel began this descent and lost its grid (another context took CUs): the slot holds the
-            // tour its last completed launch wrote back.  The per-sweep kernels count their sweeps from 0: run them on a
-            // rebased counter / cap / history and shift everything back afterwards.
-            int base = 0;
-            HIP_TRY(hipMemcpyAsync(&base, ctx->S.nsweeps + slot0, 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));
-            const HistBuf keep = ctx->hist;
-            const int hb = std::min(base, keep.cap);
-            if (keep.cap > 0) { ctx->hist.a += hb; ctx->hist.b += hb; ctx->hist.d += hb; ctx->hist.cap -= hb; }
-            drop_graphs(ctx);
-            hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, -base);
-            int rc2 = run_sweeps_plain(ctx, slot0, 1, false, max_iters, time_left_s, deadline_hit);
-            hipLaunchKernelGGL(k_rebase, dim3(1), dim3(1), 0, ctx->stream, ctx->S, slot0, base);
-            if (!rc2 && hipGetLastError() != hipSuccess) rc2 = fail(ctx, E_INTERNAL, "k_rebase launch failed");
-            ctx->hist = keep;
-            drop_graphs(ctx);
-            return rc2;
-        }
+        if (ctx->lp_handed) return run_rebased(ctx, slot0, max_iters, time_left_s, deadline_hit);
         if (ctx->opt_persist == 2) return fail(ctx, E_EXHAUSTED, "the LDS-resident descent does not apply (uint16 cells, n in [64, ~5400], one idle chip)");
+    }
+    ctx->sp_used = false;
+    bool stream = !tabu && ntours == 1 && ctx->opt_stream == 2;
+    if (!tabu && ntours == 1 && ctx->opt_stream == 1 && ctx->opt_persist == 1 && ctx->opt_kernel == 0 && ctx->opt_fused == 1) {
+        // automatic: where the LDS-resident kernels do not take the instance
+        int e_, w_, ws_, ns_;
+        size_t l_;
+        // (one 16-byte vector per thread: n <= 8192; with two the kernel is at the register limit and the one-launch-per-sweep
+        // kernel is faster: n = 12288 65.6 vs 56.5 us per sweep)
+        stream = ctx->ld / 8 <= 1024 && !persist_fits(ctx, e_, w_, l_) && (ctx->opt_persist_window == 2 || !persist_fits_w(ctx, e_, w_, l_, ws_, ns_));
+    }
+    if (stream) {
+        ctx->lp_handed = false;
+        bool ran = false;
+        const int rc = run_pstream(ctx, slot0, &time_left_s, deadline_hit, &ran);
+        if (rc) return rc;
+        if (ran) return E_OK;
+        if (ctx->lp_handed) return run_rebased(ctx, slot0, max_iters, time_left_s, deadline_hit);
+        if (ctx->opt_stream == 2) return fail(ctx, E_EXHAUSTED, "the streamed persistent descent does not apply (uint16 cells, n in [1024, 16384), one idle chip)");
     }
     return run_sweeps_plain(ctx, slot0, ntours, tabu, max_iters, time_left_s, deadline_hit);
 }
@@ -4455,6 +4691,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 93: ctx->opt_sp_nch = value == 1 || value == 2 ? (int)value : 0; break; // undocumented: vectors per thread of k_str2opt (tools/stream_probe.py)
     case 94: ctx->opt_vns_launch_k = value > 0 ? (int)std::min<long>(value, 65536) : 65536; break; // undocumented: VNS iterations per launch (tests)
     case 95: ctx->opt_lp_poll_sleep = (int)value; break; // undocumented: s_sleep(1) repetitions between polls of the exchange slots (tools/persist_probe.py)
     case 96: ctx->opt_lp_fail_at = (int)value; break; // undocumented: see opt_lp_fail_at (tests)
@@ -4468,6 +4705,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_FUSED: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad fused mode"); ctx->opt_fused = (int)value; break;
     case TSPGPU_OPT_MAX_TOURS: if (value < 1 || value > (1 << 20)) return fail(ctx, E_INVALID, "bad max tours"); ctx->opt_max_tours = (int)value; break;
     case TSPGPU_OPT_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad persist mode"); ctx->opt_persist = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
+    case TSPGPU_OPT_STREAM_PERSIST: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad stream-persist mode"); ctx->opt_stream = (int)value; ctx->lp_skip = 0; ctx->lp_backoff = 16; break;
     case TSPGPU_OPT_PERSIST_EDGES: if (value < 0 || value > LW_EMAX) return fail(ctx, E_INVALID, "edges per workgroup: 0 (auto) .. %d", LW_EMAX); ctx->opt_persist_edges = (int)value; break;
     case TSPGPU_OPT_BUILD_KERNEL: if (value < 0 || value > 1) return fail(ctx, E_INVALID, "bad build kernel"); ctx->opt_build = (int)value; break;
     case TSPGPU_OPT_PERSIST_WINDOW: if (value < 0 || value > 2) return fail(ctx, E_INVALID, "bad window mode"); ctx->opt_persist_window = (int)value; break;
@@ -4510,6 +4748,7 @@ long tspgpu_info(const tspgpu_ctx *ctx, int what)
     case 21: return ctx->lp_handed ? 1 : 0;
     case 22: return ctx->lp_sweeps;
     case 23: return ctx->vns_mode;
+    case 24: return ctx->sp_used ? 1 : 0;
     case 12: return (ctx->built && ctx->grid_ok && ctx->opt_nn != 1 && ctx->cost_bound < 134217728.0) ? ctx->grid_G : 0;
     case 13: return ctx->grid_max_occ;
     }

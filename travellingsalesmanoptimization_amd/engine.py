@@ -49,7 +49,7 @@ class Engine:
     def info(self):
         names = ["n", "ld", "elem", "kernel", "wgs_per_tour", "lds_bytes", "block", "symmetric", "cus", "depth", "matrix_free", "fused",
                  "nn_grid", "nn_grid_max_cell", "pipe2", "persist", "persist_wgs", "persist_edges", "persist_lds", "persist_window_cells",
-                 "persist_window", "persist_handed", "persist_sweeps", "vns_mode"]
+                 "persist_window", "persist_handed", "persist_sweeps", "vns_mode", "stream_persist"]
         return {k: int(self.L.tspgpu_info(self.ctx, i)) for i, k in enumerate(names)}
 
     # ---- instance
