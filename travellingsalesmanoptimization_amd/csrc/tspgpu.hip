@@ -1640,84 +1640,6 @@ __device__ __forceinline__ void pipe_stream(Best &q, const SweepArgs &A, const B
 #undef STAMP
 }
 
-// Two steps of an interval at once (uint16 cells, symmetric matrix, plain 2-opt): a wave that owns pairs of BOTH tour edges
-// of a barrier interval evaluates them as ONE instruction stream -- sixteen gathers in flight, two independent arithmetic
-// chains -- instead of one step after the other.  Why: a sweep over streamed rows is bound by the dependent chain of a
-// wave-step (three LDS round trips, ~60 dependent vector instructions: 0.3 us) with one or two active waves per SIMD, and an
-// interval ends with its slowest wave, which is the one that owns pairs of both edges (tools/stream_probe.py: 0.6 us per step
-// whatever the rows in flight).  Returns false when a chunk needs the masked variant (a's own block, a pad wave): the
-// caller then takes the two steps one after the other through sweep_step_as.
-template <int NCH>
-__device__ __forceinline__ bool sweep_step_dual(Best &q, const BState<u16, NCH> &B, const unsigned char *bS1, unsigned ldsS1, int a1, int sa1,
-                                                const v8u16 *areg1, const unsigned char *bS2, unsigned ldsS2, int a2, int sa2,
-                                                const v8u16 *areg2, int n, int BT, int tid, int wave_base)
-{
-    constexpr int V = 8;
-    const int NB = (n + 64 * V - 1) / (64 * V);
-    const int blk1 = a1 / (64 * V), blk2 = a2 / (64 * V);
-    int st1[NCH], st2[NCH];                           // per chunk: 0 not this orientation's, 1 evaluate (no mask needed)
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        const int w0 = (c * BT + wave_base) * V;
-        st1[c] = st2[c] = 0;
-        if (w0 >= n) continue;
-        if (w0 + 64 * V > n) return false;            // pad lanes: masked variant
-        const int blkb = w0 / (64 * V);
-        int d1 = blkb - blk1, d2 = blkb - blk2;
-        if (d1 < 0) d1 += NB;
-        if (d2 < 0) d2 += NB;
-        if (d1 == 0 || d2 == 0) return false;         // a's own block: masked variant
-        st1[c] = (2 * d1 < NB || (2 * d1 == NB && blk1 < blkb)) ? 1 : 0;
-        st2[c] = (2 * d2 < NB || (2 * d2 == NB && blk2 < blkb)) ? 1 : 0;
-    }
-    const int da1 = (int)reinterpret_cast<const u16 *>(bS1)[a1], da2 = (int)reinterpret_cast<const u16 *>(bS2)[a2];   // c[a][succ a] = c[succ a][a]
-    auto gather = [&](int (&g)[V], unsigned ldsS, int c) __attribute__((always_inline)) {
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-            unsigned addr;
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0"
-                : "=v"(addr) : "v"(ldsS), "v"(B.sb[c][v]));
-            g[v] = (int)*(const lds_u16 *)(uintptr_t)addr;
-        }
-    };
-    auto chain = [&](const int (&g)[V], const v8u16 &xa, int c, int a, int d_a) __attribute__((always_inline)) {
-        int m = 0x7fffffff;
-#pragma unroll
-        for (int v = 0; v < V; v++) {
-            int dl;
-            const int made = (int)xa[v] + g[v];
-            asm("v_sub_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1"
-                : "=v"(dl) : "v"(made), "v"(B.sb[c][v]));
-            m = min(m, (dl << 3) | v);
-        }
-        const int b = (c * BT + tid) * V + (m & 7);
-        const unsigned lohi = ((unsigned)min(a, b) << 16) | (unsigned)max(a, b);
-        return (long long)(((u64)(unsigned)((m >> 3) - d_a) << 32) | lohi);
-    };
-#pragma unroll
-    for (int c = 0; c < NCH; c++) {
-        if (st1[c] && st2[c]) {
-            int g1[V], g2[V];
-            gather(g1, ldsS1, c);
-            gather(g2, ldsS2, c);
-            const long long k1 = chain(g1, areg1[c], c, a1, da1), k2 = chain(g2, areg2[c], c, a2, da2);
-            const long long k = k1 < k2 ? k1 : k2;
-            q.k = k < q.k ? k : q.k;
-        } else if (st1[c]) {
-            int g1[V];
-            gather(g1, ldsS1, c);
-            const long long k = chain(g1, areg1[c], c, a1, da1);
-            q.k = k < q.k ? k : q.k;
-        } else if (st2[c]) {
-            int g2[V];
-            gather(g2, ldsS2, c);
-            const long long k = chain(g2, areg2[c], c, a2, da2);
-            q.k = k < q.k ? k : q.k;
-        }
-    }
-    return true;
-}
-
 // Streaming, second form (symmetric matrices, plain 2-opt, rows that fit LDS FOUR times): TWO tour edges per barrier
 // interval, and the row of a straight from the registers that loaded it.  In pipe_stream() a thread writes the vector
 // it fetched into LDS and reads the very same bytes back one step later as c[a][own b's] -- only the row of succ a
@@ -1731,7 +1653,7 @@ __device__ __forceinline__ bool sweep_step_dual(Best &q, const BState<u16, NCH> 
 // that owns no pair of one step usually owns pairs of the other (ownership goes by block distance from a, and a and
 // succ a sit in different blocks): the 16 waves of a workgroup idle at the barrier far less.  c[a][succ a] is read as
 // c[succ a][a] from the gather row (symmetric), so the row of a is never needed in LDS.
-template <typename T, int NCH, int PAIRS, bool DUAL = false>
+template <typename T, int NCH, int PAIRS>
 __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const BState<T, NCH> &B, T *buf, const int *nodes, unsigned lds0,
                                              int cnt, unsigned long long *stamp)
 {
@@ -1779,22 +1701,8 @@ __device__ __forceinline__ void pipe_stream2(Best &q, const SweepArgs &A, const 
     // interval gathered from; registers rotate; the pair is re-issued for the rows four intervals' worth ahead
     auto interval = [&](int s, VT(&P0)[NCH], VT(&P1)[NCH], auto tail_tag) __attribute__((always_inline)) {
         constexpr bool TAIL = decltype(tail_tag)::value;
-        bool both = false;
-        if constexpr (DUAL && sizeof(T) == 2) {
-            if ((!TAIL || s + 1 < cnt) && A.ablate != 1) {
-                const int a1 = __builtin_amdgcn_readfirstlane(nodes[s]), a2 = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
-                const int a3 = __builtin_amdgcn_readfirstlane(nodes[s + 2]);
-                const int sl1 = (s + 1) & 3, sl2 = (s + 2) & 3;
-                both = sweep_step_dual<NCH>(q, B, reinterpret_cast<const unsigned char *>(buf + (size_t)sl1 * ld),
-                                            lds0 + (unsigned)(sl1 * ld) * 2u, a1, a2, A0,
-                                            reinterpret_cast<const unsigned char *>(buf + (size_t)sl2 * ld),
-                                            lds0 + (unsigned)(sl2 * ld) * 2u, a2, a3, A1, n, BT, tid, wave_base);
-            }
-        }
-        if (!both) {
-            step(s, A0);
-            if (!TAIL || s + 1 < cnt) step(s + 1, A1);
-        }
+        step(s, A0);
+        if (!TAIL || s + 1 < cnt) step(s + 1, A1);
         if (stamp && tid == 0 && s < 24) stamp[8 + s] = wall_clock64();
         if (!TAIL || s + 3 <= cnt) land(P0, s + 3);
         if (!TAIL || s + 4 <= cnt) land(P1, s + 4);
