@@ -652,8 +652,8 @@ def test_host_tabu_search_other_policies(host, O, policy, tenure_of):
 @pytest.mark.gpu
 def test_host_lazy_costs(host, O, golden):
     """tsp_lazy_costs (what the `tsp` executable runs with): tsp_compute_costs builds the matrix on the device only,
-    tsp_inst.costs stays NULL -- the heuristic entry points take it as "the instance's matrix" --, and the first tsp_get_cost
-    downloads it; the same results as with the eager copy"""
+    tsp_inst.costs stays NULL -- the heuristic entry points take it as "the instance's matrix" --, tsp_get_cost computes single
+    weights on demand, and only an explicit tsp_host_costs() downloads the matrix; the same results as with the eager copy"""
     import numpy as np
     lazy = C.c_bool.in_dll(host, "tsp_lazy_costs")
     host.tsp_get_cost.restype = C.c_double
@@ -674,9 +674,14 @@ def test_host_lazy_costs(host, O, golden):
         assert not inst.costs                                   # the whole heuristic path ran without a host matrix
         xy, _ = O.read_tsplib(os.path.join(DATA, "pr1002.tsp"))
         c = O.cost_matrix(xy)
-        assert host.tsp_get_cost(3, 977) == c[3, 977] and inst.costs    # first read: downloaded
+        # single lookups are computed on demand (the reference's arithmetic, bit-identical to the device matrix): no download
+        for i, j in ((3, 977), (977, 3), (0, 1), (500, 500), (1001, 0)):
+            assert host.tsp_get_cost(i, j) == c[i, j]
+        assert not inst.costs
+        host.tsp_host_costs.restype = C.c_void_p
+        assert host.tsp_host_costs() and inst.costs                     # the explicit call materialises it
         got = np.ctypeslib.as_array(C.cast(inst.costs, C.POINTER(C.c_double)), shape=(n, n))
-        assert np.array_equal(got, c)
+        assert np.array_equal(got, c) and host.tsp_get_cost(3, 977) == c[3, 977]
     finally:
         lazy.value = False
         host.tsp_free_instance()

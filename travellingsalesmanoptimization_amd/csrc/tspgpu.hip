@@ -3944,11 +3944,6 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
             }
         }
         if (ctx->opt_timing) HIP_TRY(hipEventRecord(ctx->ev[1], ctx->stream));
-        if (tabu || vns) {
-            hipLaunchKernelGGL(k_lds_best_succ, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lp_best, ctx->d_lp_best + ctx->ld,
-                               ctx->d_best_succ, ctx->n);
-            HIP_TRY(hipGetLastError());
-        }
         HIP_TRY(hipMemcpyAsync(ctx->h_lp, d_ctl, 32, hipMemcpyDeviceToHost, ctx->stream));
         if (vns) HIP_TRY(hipMemcpyAsync(ctx->h_lp + 8, reinterpret_cast<char *>(ctx->d_tabu) + offsetof(TabuState, best_cost), 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -3971,6 +3966,15 @@ static int run_persist(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         first = false;
         ctx->lp_backoff = 16;
         ctx->lp_sweeps += sd;
+        if (tabu || vns) {
+            // the launch completed: its best tour (written by array cell, every workgroup its own cells) becomes the successor
+            // array.  Only now -- a launch that lost its grid half way leaves a MIXTURE of old and new cells in best_ord
+            // (the workgroups that passed the last exchange wrote theirs, the one that timed out did not), and d_best_succ
+            // must keep the last good launch's tour for the hand-over
+            hipLaunchKernelGGL(k_lds_best_succ, dim3((ctx->n + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_lp_best, ctx->d_lp_best + ctx->ld,
+                               ctx->d_best_succ, ctx->n);
+            HIP_TRY(hipGetLastError());
+        }
         if (ctx->opt_timing && sd > 0) {
             float ms = 0;
             HIP_TRY(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));

@@ -6,6 +6,7 @@
 #include "tsp_model.h"
 
 #include <libgen.h>
+#include <pthread.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -247,19 +248,26 @@ ERROR_CODE tsp_compute_costs(void)
 }
 
 /* the host copy of the matrix (row-major n x n doubles, what the reference's tsp_inst.costs holds), downloaded from the
- * device on first use when tsp_lazy_costs kept it away; NULL in matrix-free mode or when the allocation fails */
+ * device by an EXPLICIT call when tsp_lazy_costs kept it away (2.74 GB for d18512: nothing on the heuristic path reads it);
+ * NULL in matrix-free mode or when the allocation fails.  Serialised: two threads asking at once get one download. */
+static pthread_mutex_t host_costs_mu = PTHREAD_MUTEX_INITIALIZER;
 double *tsp_host_costs(void)
 {
     if (tsp_inst.costs || tsp_matrix_free || tsp_inst.nnodes <= 0) return tsp_inst.costs;
-    struct tspgpu_ctx *g = tsp_gpu();
-    if (!g) return NULL;
-    const size_t n = (size_t)tsp_inst.nnodes;
-    double *c = (double *)malloc(n * n * sizeof(double));
-    if (!c) { log_error("host copy of the cost matrix: out of memory (%zu bytes)", n * n * sizeof(double)); return NULL; }
-    const int rc = tspgpu_get_costs(g, c);
-    if (rc) { log_error("tspgpu_get_costs: %s", tspgpu_last_error(g)); free(c); return NULL; }
-    tsp_inst.costs = c;
-    return c;
+    pthread_mutex_lock(&host_costs_mu);
+    if (!tsp_inst.costs) {
+        struct tspgpu_ctx *g = tsp_gpu();
+        const size_t n = (size_t)tsp_inst.nnodes;
+        double *c = g ? (double *)malloc(n * n * sizeof(double)) : NULL;
+        if (g && !c) log_error("host copy of the cost matrix: out of memory (%zu bytes)", n * n * sizeof(double));
+        if (c) {
+            const int rc = tspgpu_get_costs(g, c);
+            if (rc) { log_error("tspgpu_get_costs: %s", tspgpu_last_error(g)); free(c); c = NULL; }
+        }
+        if (c) __atomic_store_n(&tsp_inst.costs, c, __ATOMIC_RELEASE);
+    }
+    pthread_mutex_unlock(&host_costs_mu);
+    return tsp_inst.costs;
 }
 
 /* one weight on the host with the arithmetic of tsp.c:629 (and TSPLIB's for ATT / CEIL_2D) */
@@ -273,10 +281,12 @@ static double host_weight(int i, int j)
     return ceil(sqrt(sq));
 }
 
-/* tsp.c:638-640.  Matrix-free instances (and a lazy copy that could not be allocated) compute the weight on demand. */
+/* tsp.c:638-640.  While no host copy exists (matrix-free instances; the lazy mode of the `tsp` executable) the weight is
+ * computed on demand with the reference's arithmetic -- bit-identical to the device matrix (tests) -- instead of downloading
+ * n x n doubles to serve an O(n) lookup (ref_2opt's past-deadline branch, tsp_solution_cost: ADVICE r3). */
 double tsp_get_cost(int i, int j)
 {
-    const double *c = tsp_inst.costs ? tsp_inst.costs : (tsp_lazy_costs ? tsp_host_costs() : NULL);
+    const double *c = __atomic_load_n(&tsp_inst.costs, __ATOMIC_ACQUIRE);
     return c ? c[(size_t)i * tsp_inst.nnodes + j] : host_weight(i, j);
 }
 
