@@ -412,6 +412,45 @@ def main():
         return {"golden": f"tests/golden/golden_n4096_multistart.json ({len(want)} starts, compiled reference)", "ok": bool(ok),
                 "per_start_checked": int(min(check_slots, len(want))), "per_start_ok": int(slots_ok), **got}
 
+    def batch_measure(e, nstarts):
+        """All-NN + 2-opt over starts 0..nstarts-1 of the resident instance in ONE batched call (h_greedy_2opt's loop,
+        heuristics.c:74-116; what h_Greedy_2opt_mod_costs runs on a caller's f64 matrix): wall-clock, parity gate against the
+        compiled reference's per-start goldens, and the dominant kernel's own time from HIP events"""
+        starts = np.arange(nstarts, dtype=np.int32)
+        e.multistart_nn_2opt(starts[:4])
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        res = e.multistart_nn_2opt(starts)
+        dtb = time.perf_counter() - t1
+        info_b = e.info()
+        gate_b = multistart_gate(e, starts, res)
+        if gate_b.get("golden") and not gate_b["ok"]:
+            raise SystemExit(f"parity gate of the batched multi-start failed: {gate_b}")
+        bpe = 2 * BYTES[info_b["elem"]]
+        # the same call once more with HIP events around every sweep launch of the batch (graphs off): the dominant kernel's
+        # own time.  One launch sweeps every live tour of the batch: its algorithmic bytes = live tours x evals x bpe
+        e.set_option(T.OPT_TIMING, 1); e.timing_read(reset=True)
+        res_t = e.multistart_nn_2opt(starts)
+        ms_total, launches = e.timing_read(reset=True)
+        e.set_option(T.OPT_TIMING, 0)
+        ach = res_t["sweeps"] * evals * bpe / (ms_total * 1e-3) / 1e9
+        return {"starts": int(nstarts), "matrix_elem": NAMES[info_b["elem"]], "sweeps": int(res["sweeps"]), "seconds": dtb,
+                "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"], "best_start": int(res["start"]),
+                "parity": gate_b,
+                "includes": "NN construction + 2-opt of every start, host arrays in/out",
+                "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                             "traffic": None, "traffic_from_committed_profile": load_traffic(f"n{n}_{NAMES[info_b['elem']]}_batch{nstarts}"),
+                             "kernel": f"k_sweep_pipe<{CTYPE[info_b['elem']]}> (rows streamed, runs of {info_b['wgs_per_tour']} workgroups per tour; one launch sweeps every live tour of the batch)",
+                             "kernel_ms_mean": ms_total / max(launches, 1), "kernel_launches_timed": int(launches),
+                             "algorithmic_bytes_per_launch": res_t["sweeps"] * evals * bpe / max(launches, 1),
+                             "mean_live_tours_per_launch": res_t["sweeps"] / max(launches, 1), "bytes_per_eval": bpe,
+                             "note": "HIP events around every sweep launch of a second, identical call (k_apply and NN are outside); the "
+                                     "tours of a batch share one matrix the last-level cache holds, so these are nominal bytes "
+                                     "(SURVEY 8d), not HBM traffic"},
+                # SURVEY 8(d)'s convention over the whole call (NN + sweeps + applies, host in/out)
+                "nominal_hbm": {"bytes_per_eval": bpe, "achieved_GBs": res["sweeps"] * evals * bpe / dtb / 1e9,
+                                "peak_GBs": HBM_PEAK_GBS, "frac": res["sweeps"] * evals * bpe / dtb / 1e9 / HBM_PEAK_GBS}}
+
     def search_row(n, seed, steps, warmup, elem, cpu_sweeps, port):
         """one row of the throughput table on its own engine (single GPU)"""
         evals = T.evals_per_sweep(n)
@@ -603,7 +642,9 @@ def main():
                 dt2 = time.perf_counter() - t1
                 p2, c2, _ = e2.tour_store(1)
                 r2 = timed_search(e2, evals)
-                return {"matrix_elem": oelem, "value": sw2 * evals / dt2, "unit": "evals/s", "ms_per_step": 1e3 * dt2 / args.steps,
+                # the regime the reference's f64 caller runs in (h_Greedy_2opt_mod_costs: all starts, batched): VERDICT r3 item 6
+                b2b = guarded(batch_measure, e2, args.batch_starts) if args.batch_starts > 0 else None
+                return {"matrix_elem": oelem, "batch": b2b, "value": sw2 * evals / dt2, "unit": "evals/s", "ms_per_step": 1e3 * dt2 / args.steps,
                         "final_cost": c2, "parity": parity(n, seed, sw2 // args.steps, c2, p2), "roofline": r2, "roofline_build": b2,
                         # (flat copies of the two figures round 1 printed)
                         "kernel_ms_mean": r2["kernel_ms_mean"], "bytes_per_eval": r2["bytes_per_eval"],
@@ -617,40 +658,7 @@ def main():
     batch = None
     if aux and args.batch_starts > 0:
         def batch_leg():
-            starts = np.arange(args.batch_starts, dtype=np.int32)
-            eng.multistart_nn_2opt(starts[:4])
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            res = eng.multistart_nn_2opt(starts)
-            dtb = time.perf_counter() - t1
-            info_b = eng.info()
-            gate_b = multistart_gate(eng, starts, res)
-            if gate_b.get("golden") and not gate_b["ok"]:
-                raise SystemExit(f"parity gate of the batched multi-start failed: {gate_b}")
-            bpe = 2 * BYTES[info_b["elem"]]
-            # the same call once more with HIP events around every sweep launch of the batch (graphs off): the dominant kernel's
-            # own time.  One launch sweeps every live tour of the batch: its algorithmic bytes = live tours x evals x bpe
-            eng.set_option(T.OPT_TIMING, 1); eng.timing_read(reset=True)
-            res_t = eng.multistart_nn_2opt(starts)
-            ms_total, launches = eng.timing_read(reset=True)
-            eng.set_option(T.OPT_TIMING, 0)
-            ach = res_t["sweeps"] * evals * bpe / (ms_total * 1e-3) / 1e9
-            return {"starts": int(args.batch_starts), "sweeps": int(res["sweeps"]), "seconds": dtb,
-                    "value": res["sweeps"] * evals / dtb, "unit": "evals/s", "best_cost": res["cost"], "best_start": int(res["start"]),
-                    "parity": gate_b,
-                    "includes": "NN construction + 2-opt of every start, host arrays in/out",
-                    "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                                 "traffic": None, "traffic_from_committed_profile": load_traffic(f"n{n}_{NAMES[info_b['elem']]}_batch{args.batch_starts}"),
-                                 "kernel": "k_sweep_pipe (rows streamed, runs of n/64 edges; one launch sweeps every live tour of the batch)",
-                                 "kernel_ms_mean": ms_total / max(launches, 1), "kernel_launches_timed": int(launches),
-                                 "algorithmic_bytes_per_launch": res_t["sweeps"] * evals * bpe / max(launches, 1),
-                                 "mean_live_tours_per_launch": res_t["sweeps"] / max(launches, 1), "bytes_per_eval": bpe,
-                                 "note": "HIP events around every sweep launch of a second, identical call (k_apply and NN are outside); the "
-                                         "tours of a batch share one 33.5 MB matrix, so part of these bytes are last-level-cache hits"},
-                    # SURVEY 8(d)'s convention over the whole call (NN + sweeps + applies, host in/out)
-                    "nominal_hbm": {"bytes_per_eval": bpe, "achieved_GBs": res["sweeps"] * evals * bpe / dtb / 1e9,
-                                    "peak_GBs": HBM_PEAK_GBS, "frac": res["sweeps"] * evals * bpe / dtb / 1e9 / HBM_PEAK_GBS,
-                                    "kernel": "k_sweep_pipe (rows streamed, runs of n/64 edges)"}}
+            return batch_measure(eng, args.batch_starts)
         batch = guarded(batch_leg)
 
     # ---- the other rows of north_star's throughput table (n = 1k / 16k), each on its own engine

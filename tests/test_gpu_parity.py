@@ -1903,6 +1903,30 @@ def test_matrix_triangle_kernel_bit_exact(eng, T, O, n, kind, elem, build):
         eng.set_option(T.OPT_BUILD_KERNEL, 0)
 
 
+@pytest.mark.parametrize("n,kind", [(1024, "EUC_2D"), (1025, "CEIL_2D"), (1151, "ATT"), (1152, "EUC_2D"), (2175, "EUC_2D"), (8200, "EUC_2D")])
+def test_matrix_triangle_kernel_128_tiles_bit_exact(eng, T, O, n, kind):
+    """the 128 x 128 form of the triangle kernel (k_build_costs_tri128: the default from n = 8192 up, forced here by hook 92
+    at the smaller sizes): all n x n cells against the oracle, sizes around the tile edges (n % 128 = 0, 1, 127), padded
+    rows, the three weight kinds, non-integer coordinates"""
+    r = np.random.RandomState(n)
+    xy = r.uniform(-5000, 5000, size=(n, 2)) if kind == "EUC_2D" else np.floor(r.uniform(0, 9000, size=(n, 2)))
+    k = {"EUC_2D": O.EUC_2D, "ATT": O.ATT, "CEIL_2D": O.CEIL_2D}[kind]
+    eng.set_option(T.OPT_ELEM, 3); eng.set_option(T.OPT_KERNEL, 0); eng.set_option(T.OPT_BUILD_KERNEL, 0); eng.set_option(92, 128)
+    try:
+        eng.set_points(xy, {"EUC_2D": T.EUC_2D, "ATT": T.ATT, "CEIL_2D": T.CEIL_2D}[kind])
+        got = eng.build_costs(fetch=True)
+        assert eng.info()["elem"] == 3
+        if n <= 2500:
+            c = O.cost_matrix(xy, k)
+            bad = np.argwhere(got != c)
+            assert len(bad) == 0, (bad[:5], got[tuple(bad[0])], c[tuple(bad[0])])
+        else:                                   # row by row (the oracle's full matrix would take a minute)
+            rows = np.unique(np.concatenate([np.arange(0, n, 61), np.arange(n - 130, n)])).astype(np.int32)
+            assert np.array_equal(got[rows], O.cost_rows(xy, rows, k)) and np.array_equal(got, got.T)
+    finally:
+        eng.set_option(92, 0)
+
+
 def test_vns_search_relaunches_and_grid_loss(T, O, instances):
     """the resident VNS walk in launches of 7 iterations (test hook 94) equals the oracle's walk; and when the grid loses its
     co-residency after the first launch (hook 96: the next four launches fail their rendezvous) the walk goes on with one

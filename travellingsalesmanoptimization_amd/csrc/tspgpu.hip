@@ -391,6 +391,73 @@ __global__ void __launch_bounds__(256) k_build_costs_tri(const double2 *__restri
     if (jt < n) *reinterpret_cast<vec16 *>(out + (size_t)jt * ld + it0) = *reinterpret_cast<const vec16 *>(TT + r * STR + c0);
 }
 
+// The same with 128 x 128 tiles (round 4, n >= 1024): thread (rg, cc) of 32 x 8 takes rows rg, rg + 32, rg + 64, rg + 96 and columns
+// 16 cc .. 16 cc + 15 of the tile, so that one store instruction writes eight 256-byte row segments (the 64 x 64 form: sixteen
+// 128-byte ones, 8 KB apart -- its transposed half stored at about a third of the rate of whole rows); the thread's 16 column
+// points stay in registers over its four rows.
+constexpr int TRIB = 128;
+template <typename T, int KIND, bool F32R>
+__global__ void __launch_bounds__(256) k_build_costs_tri128(const double2 *__restrict__ pts, int n, int ld, int NT, T *__restrict__ out)
+{
+    constexpr int STR = TRIB + 16 / (int)sizeof(T);       // transposed tile's row stride: rows stay 16-byte aligned
+    __shared__ double2 P[2 * TRIB];
+    __shared__ __attribute__((aligned(16))) T TT[TRIB * STR];
+    int I = 0, rest = (int)blockIdx.x;
+    {
+        const float a = (float)(2 * NT + 1);
+        I = (int)((a - __builtin_sqrtf(a * a - 8.0f * (float)rest)) * 0.5f);
+        I = max(0, min(I, NT - 1));
+        while (I > 0 && I * NT - I * (I - 1) / 2 > rest) I--;
+        while (I + 1 < NT && (I + 1) * NT - (I + 1) * I / 2 <= rest) I++;
+        rest -= I * NT - I * (I - 1) / 2;
+    }
+    const int J = I + rest;
+    const int tid = (int)threadIdx.x, rg = tid >> 3, c0 = (tid & 7) * 16;
+    P[tid] = pts[min((tid < TRIB ? I : J) * TRIB + (tid & (TRIB - 1)), n - 1)];
+    __syncthreads();
+    double2 pj[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) pj[k] = P[TRIB + c0 + k];
+    const int j0 = J * TRIB + c0;
+    const bool inner = I != J && (J + 1) * TRIB <= n;     // no diagonal cell, no column past n: no masks (workgroup-uniform)
+    typedef T vec16 __attribute__((ext_vector_type(16)));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = rg + 32 * q, i = I * TRIB + r;
+        const double2 pi = P[r];
+        T w[16];
+        if (inner) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) w[k] = (T)edge_w<KIND, F32R>(pi.x, pi.y, pj[k].x, pj[k].y);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const int j = j0 + k;
+                const int v = edge_w<KIND, F32R>(pi.x, pi.y, pj[k].x, pj[k].y);
+                w[k] = j >= n ? (T)0 : j == i ? (T)-1 : (T)v;
+            }
+        }
+        if (i < n && j0 < ld) {
+            vec16 o;
+#pragma unroll
+            for (int k = 0; k < 16; k++) o[k] = w[k];
+            *reinterpret_cast<vec16 *>(out + (size_t)i * ld + j0) = o;
+        }
+        if (I != J) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) TT[(c0 + k) * STR + r] = w[k];
+        }
+    }
+    if (I == J) return;                                    // (a diagonal tile is its own transpose)
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int r = rg + 32 * q;
+        const int jt = J * TRIB + r, it0 = I * TRIB + c0;  // row of tile (J, I), its first column (I < J: every column < n)
+        if (jt < n) *reinterpret_cast<vec16 *>(out + (size_t)jt * ld + it0) = *reinterpret_cast<const vec16 *>(TT + r * STR + c0);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) k_build_costs(const double2 *__restrict__ pts, int n, int ld, int kind,
                                                      T *__restrict__ out)
@@ -3001,6 +3068,7 @@ struct tspgpu_ctx {
     // LDS-resident descent (k_lds2opt): exchange slots + control words, allocated on first use
     int opt_persist = 1;       // 0 never, 1 where it applies (uint16 cells, one tour, n <= 4096, a whole idle chip), 2 or fail
     int opt_persist_edges = 0; // tour edges per workgroup (0 = auto)
+    int opt_build_tile = 0;     // probe hook 92: 64 = the 64 x 64 tiles at every size
     int opt_build = 0;          // K1 for integer cells: 0 one triangle + transposed store (k_build_costs_tri), 1 every cell computed (k_build_costs_int)
     int opt_persist_window = 0; // 0 auto (half-window rows where whole rows do not fit the chip's LDS), 1 always, 2 never
     bool lp_window = false;    // ... and it was the half-window form (k_lds2opt_w)
@@ -4603,6 +4671,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 92: ctx->opt_build_tile = (int)value; break; // undocumented: tile of the triangle build (tools/build_probe.py)
     case 93: ctx->opt_sp_nch = value == 1 || value == 2 ? (int)value : 0; break; // undocumented: vectors per thread of k_str2opt (tools/stream_probe.py)
     case 94: ctx->opt_vns_launch_k = value > 0 ? (int)std::min<long>(value, 65536) : 65536; break; // undocumented: VNS iterations per launch (tests)
     case 95: ctx->opt_lp_poll_sleep = (int)value; break; // undocumented: s_sleep(1) repetitions between polls of the exchange slots (tools/persist_probe.py)
@@ -4713,7 +4782,13 @@ static int launch_build(tspgpu_ctx *ctx)
         // arithmetic they save -- measured 27.5 vs 16.7 us at n=4096, tools/build_probe.py)
         const bool tri = ctx->opt_build == 0 && ctx->elem == TSPGPU_ELEM_U16 && n >= 2 * TRI && NT <= 2047;
         const bool f32r = kind == TSPGPU_EUC_2D && ctx->cost_bound < 4.0e6;      // (every root below 2^22)
-#define BUILD_INT(T, K) do { if (tri && f32r && K == TSPGPU_EUC_2D) hipLaunchKernelGGL((k_build_costs_tri<T, TSPGPU_EUC_2D, true>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
+        // 128 x 128 tiles (256-byte row segments in both halves) from n = 8192 up: measured (tools/build_probe.py) n = 16384 123 vs
+        // 131 us, but n = 4096 15.4 vs 11.8 us -- 528 workgroups of four times the arithmetic fill the chip worse than 2080
+        const bool big = tri && ctx->opt_build_tile != 64 && (n >= 8192 || (ctx->opt_build_tile == 128 && n >= 1024));
+        const int NTB = (n + TRIB - 1) / TRIB;
+#define BUILD_INT(T, K) do { if (big && f32r && K == TSPGPU_EUC_2D) hipLaunchKernelGGL((k_build_costs_tri128<T, TSPGPU_EUC_2D, true>), dim3(NTB * (NTB + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NTB, (T *)ctx->d_mat); \
+                             else if (big) hipLaunchKernelGGL((k_build_costs_tri128<T, K, false>), dim3(NTB * (NTB + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NTB, (T *)ctx->d_mat); \
+                             else if (tri && f32r && K == TSPGPU_EUC_2D) hipLaunchKernelGGL((k_build_costs_tri<T, TSPGPU_EUC_2D, true>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
                              else if (tri) hipLaunchKernelGGL((k_build_costs_tri<T, K, false>), dim3(NT * (NT + 1) / 2), dim3(256), 0, ctx->stream, ctx->d_pts, n, ld, NT, (T *)ctx->d_mat); \
                              else hipLaunchKernelGGL((k_build_costs_int<T, K>), dim3((ld / (16 / (int)sizeof(T)) + 255) / 256, (n + BUILD_ROWS - 1) / BUILD_ROWS), dim3(256), 0, ctx->stream, \
                                                      ctx->d_pts, n, ld, (T *)ctx->d_mat); } while (0)
