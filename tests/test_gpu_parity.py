@@ -1927,6 +1927,90 @@ def test_matrix_triangle_kernel_128_tiles_bit_exact(eng, T, O, n, kind):
         eng.set_option(92, 0)
 
 
+# ------------------------------------------------------------------ randomized differential test over the option space
+def _fuzz_instance(r, O, n):
+    """a random instance of one of the shapes that have bitten before: uniform (non-integer), small integer lattice (ties
+    everywhere), clusters with duplicates, a caller matrix that is symmetric and integer but not metric"""
+    shape = r.randint(4)
+    if shape == 0:
+        xy = r.uniform(-5000, 5000, size=(n, 2))
+    elif shape == 1:
+        xy = r.randint(0, max(3, int(np.sqrt(n)) + 2), size=(n, 2)).astype(np.float64) * 10.0
+    elif shape == 2:
+        cen = r.uniform(0, 20000, size=(max(2, n // 25), 2))
+        xy = np.floor(cen[r.randint(len(cen), size=n)] + r.normal(0, 40.0, size=(n, 2)))
+    else:
+        m = r.randint(1, 60, size=(n, n)).astype(np.float64)
+        m = np.triu(m, 1); m = m + m.T
+        np.fill_diagonal(m, -1.0)
+        return None, m
+    return xy, None
+
+
+_FUZZ_TALLY = {"ran": 0, "refused": 0, "sweeps": 0}
+
+
+@pytest.mark.parametrize("seed", range(80))
+def test_random_configurations_against_the_oracle(eng, T, O, seed):
+    """differential fuzz: a random instance (uniform / lattice / clustered points in one of the three weight kinds, or a
+    caller matrix), a random start tour (NN from a random node, or a random permutation), and a random point of the
+    engine's option space -- matrix storage, sweep kernel, launch structure (one launch per descent LDS-resident / half
+    windows / streamed, one launch per sweep, sweep + apply), matrix-free, block size, workgroups per tour -- against the
+    oracle: every move (a, b, delta) of up to 60 sweeps, the tour and its cost afterwards"""
+    r = np.random.RandomState(1000 + seed)
+    n = int(r.choice([r.randint(8, 64), r.randint(64, 300), r.randint(300, 1300)]))
+    xy, m = _fuzz_instance(r, O, n)
+    kind = int(r.randint(3)) if xy is not None else 0
+    c = O.cost_matrix(xy, kind) if xy is not None else m
+    elem = int(r.choice([0, 1, 2, 3]))
+    kernel = int(r.choice([0, 0, 1, 2, 3]))
+    fused = int(r.choice([0, 1, 2]))
+    persist = int(r.choice([0, 1, 1]))
+    window = int(r.choice([0, 1, 2]))
+    stream = int(r.choice([1, 1, 2])) if n >= 1024 else 1
+    mfree = int(r.choice([2, 2, 1])) if xy is not None else 2
+    opts = dict(n=n, kind=kind, elem=elem, kernel=kernel, fused=fused, persist=persist, window=window, stream=stream, mfree=mfree,
+                matrix=xy is None)
+    try:
+        eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel); eng.set_option(T.OPT_FUSED, fused)
+        eng.set_option(T.OPT_PERSIST, persist); eng.set_option(T.OPT_PERSIST_WINDOW, window); eng.set_option(T.OPT_STREAM_PERSIST, stream)
+        eng.set_option(T.OPT_MATRIX_FREE, mfree)
+        eng.set_option(T.OPT_PERSIST_EDGES, int(r.choice([0, 0, 3, 7])))
+        if xy is not None:
+            eng.set_points(xy, kind); eng.build_costs()
+        else:
+            eng.set_costs(m)
+        if r.randint(2):
+            succ, cost = O.nn_tour(c, int(r.randint(n)))
+        else:
+            perm = r.permutation(n).astype(np.int32)
+            succ = np.empty(n, dtype=np.int32); succ[perm] = np.roll(perm, -1)
+            cost = O.tour_cost(c, succ)
+        try:
+            sw = _descent_against_oracle(eng, O, c, succ, cost, 60)
+        except T.TspGpuError as e:
+            # combinations that do not exist must fail loudly with the documented codes, never run something else silently
+            assert e.code in (8, 9, 3), (e, opts)
+            _FUZZ_TALLY["refused"] += 1
+            return
+        assert 1 <= sw <= 60, opts
+        _FUZZ_TALLY["ran"] += 1
+        _FUZZ_TALLY["sweeps"] += sw
+    except AssertionError as e:
+        raise AssertionError(f"{opts}: {e}") from e
+    finally:
+        for o, v in ((T.OPT_ELEM, 0), (T.OPT_KERNEL, 0), (T.OPT_FUSED, 1), (T.OPT_PERSIST, 1), (T.OPT_PERSIST_WINDOW, 0),
+                     (T.OPT_STREAM_PERSIST, 1), (T.OPT_MATRIX_FREE, 0), (T.OPT_PERSIST_EDGES, 0)):
+            eng.set_option(o, v)
+
+
+def test_random_configurations_mostly_ran(capsys):
+    """(runs after the 80 seeds above) the fuzz is only worth something if most configurations exist and ran"""
+    with capsys.disabled():
+        print(f"\n[fuzz] {_FUZZ_TALLY}")
+    assert _FUZZ_TALLY["ran"] >= 60 and _FUZZ_TALLY["sweeps"] >= 1200, _FUZZ_TALLY
+
+
 def test_vns_search_relaunches_and_grid_loss(T, O, instances):
     """the resident VNS walk in launches of 7 iterations (test hook 94) equals the oracle's walk; and when the grid loses its
     co-residency after the first launch (hook 96: the next four launches fail their rendezvous) the walk goes on with one
