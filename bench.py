@@ -373,7 +373,8 @@ def main():
         ach = nbytes / (ms * 1e-3) / 1e9
         return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None, "kernel_ms_mean": ms,
-                "kernel": "k_build_costs<double>" if info["elem"] == T.ELEM_F64 else (f"k_build_costs_tri<{CTYPE[info['elem']]}, kind> (upper triangle computed once, every 64 x 64 tile stored twice)" if info["n"] >= 128 and info["elem"] == T.ELEM_U16 else f"k_build_costs_int<{CTYPE[info['elem']]}, kind>"),
+                "kernel": "k_build_costs<double>" if info["elem"] == T.ELEM_F64 else ((f"k_build_costs_tri128<{CTYPE[info['elem']]}, kind> (upper triangle computed once, every 128 x 128 tile stored twice)" if info["n"] >= 8192 else
+                            f"k_build_costs_tri<{CTYPE[info['elem']]}, kind> (upper triangle computed once, every 64 x 64 tile stored twice)") if info["n"] >= 128 and info["elem"] == T.ELEM_U16 else f"k_build_costs_int<{CTYPE[info['elem']]}, kind>"),
                 "algorithmic_bytes_per_launch": nbytes, "bytes_per_cell": BYTES[info["elem"]],
                 "f64_cells_equivalent_GBs": 8 * info["n"] * info["ld"] / (ms * 1e-3) / 1e9}
 

@@ -37,6 +37,12 @@ for tag, key in (("n8192", "n8192_u16_stream_persist"), ("n4096", "n4096_u16_per
     if (tag, "FETCH_SIZE") in tot_all and (tag, "WRITE_SIZE") in tot_all:
         f, nf = tot_all[(tag, "FETCH_SIZE")]; w, nw = tot_all[(tag, "WRITE_SIZE")]
         traffic[key] = (f / nf + w / nw) / sw[tag]
+# the batched multi-start: all k_sweep_pipe launches of the run (warm-up of starts 0..7 + the 64-start call) sweep
+# 4 975 + 39 911 tour-sweeps (golden_n4096_multistart.json); per launch of the 64-start call 60.47 tours are live on average
+if ("batch", "FETCH_SIZE") in tot_all and ("batch", "WRITE_SIZE") in tot_all:
+    per_tour_sweep = (tot_all[("batch", "FETCH_SIZE")][0] + tot_all[("batch", "WRITE_SIZE")][0]) / (4975 + 39911)
+    traffic["n4096_u16_batch64"] = per_tour_sweep * 39911 / 660
+    traffic["n4096_u16_batch64_per_tour_sweep"] = per_tour_sweep
 json.dump(traffic, open(tpath, "w"), indent=1)
 for f, dst, head in (("lds_phases.txt", "r04_lds_phase_clocks.txt", "python3 tools/persist_probe.py 4096 1024"),
                      ("stream_phases.txt", "r04_stream_phase_clocks.txt", "python3 tools/stream_probe.py 5600 8192"),
