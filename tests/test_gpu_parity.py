@@ -277,6 +277,31 @@ def test_published_nn_columns_engine(eng, T, O, name):
         eng.set_option(T.OPT_NN_KERNEL, 0); eng.set_option(T.OPT_MATRIX_FREE, 0)
 
 
+@pytest.mark.parametrize("path", ["default", "one_launch_per_sweep", "f64_cells", "matrix_free"])
+@pytest.mark.parametrize("name", sorted(_published()))
+def test_published_instances_two_opt_descent(eng, T, O, name, path):
+    """the 14 instances of the reference's published table, NN(0) -> 2-opt local optimum against the COMPILED REFERENCE's run
+    on the same file (sweeps, final cost, tour hash: tests/golden/published_heuristics_ric.json, two_opt_from_nn0): the
+    default path (the LDS-resident descent), one launch per sweep, the reference's f64 cells, and on-the-fly distances --
+    non-integer coordinates (u1060, u1817, fl1400, fl1577, d1291, d1655), heavy clustering (fl*), ties"""
+    g = _published()[name]["two_opt_from_nn0"]
+    xy, _ = O.read_tsplib(data_path(name))
+    try:
+        eng.set_option(T.OPT_ELEM, 1 if path == "f64_cells" else 0); eng.set_option(T.OPT_KERNEL, 0)
+        eng.set_option(T.OPT_PERSIST, 0 if path in ("one_launch_per_sweep", "f64_cells") else 1)
+        eng.set_option(T.OPT_MATRIX_FREE, 1 if path == "matrix_free" else 2)
+        eng.set_points(xy); eng.build_costs()
+        succ, nn_cost = eng.nn_tour(0)
+        assert nn_cost == _published()[name]["NN"] and fx(O, succ) == g["nn_fnv"]
+        cost, sweeps, rc = eng.two_opt(succ)
+        info = eng.info()
+        assert rc == 0 and (sweeps, cost, fx(O, succ)) == (g["sweeps"], g["final_cost"], g["final_fnv"]), info
+        assert info["persist"] == (1 if path == "default" else 0) and info["matrix_free"] == (1 if path == "matrix_free" else 0)
+        assert info["elem"] == (1 if path == "f64_cells" else 2 if path == "matrix_free" else 3)
+    finally:
+        eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_PERSIST, 1); eng.set_option(T.OPT_MATRIX_FREE, 0)
+
+
 # ------------------------------------------------------------------ K2/K4 sweeps
 @pytest.fixture(params=[2, 0], ids=["fused", "split"])
 def fused(request, eng, T):
@@ -1571,6 +1596,61 @@ def test_stream_persist_is_the_default_past_the_lds_sizes(eng, T, O):
         assert gcost == ocost and np.array_equal(g, o)
     finally:
         eng.set_option(T.OPT_HISTORY, 0)
+
+
+def test_stream_persist_hands_over_mid_descent(T, O):
+    """the same for the streamed persistent descent: a deadline-bounded descent relaunches k_str2opt per sweep budget; when a
+    LATER launch no longer gets the whole chip (test hook 96: the 2nd .. 5th launch fail their rendezvous) the rest of the
+    descent runs one launch per sweep from the tour the last completed launch wrote back, on a rebased sweep counter /
+    history -- one state: valid tour, its cost, the sweep count = the history's length, every move the oracle's; and a first
+    launch that fails its rendezvous (hook 97: workgroup 0 withholds its record) leaves the whole descent to that path"""
+    e = T.Engine(0)
+    try:
+        n = 2000
+        xy = O.random_points(n, 77)
+        c = O.cost_matrix(xy)
+        e.set_option(T.OPT_ELEM, 3); e.set_option(T.OPT_PERSIST, 0); e.set_option(T.OPT_STREAM_PERSIST, 2)
+        e.set_points(xy); e.build_costs()
+        succ0, cost0 = O.nn_tour(c, 0)
+        e.set_option(T.OPT_HISTORY, 4096)
+
+        def check(g, gcost, sweeps, rc):
+            a, b, d = e.history(4096)
+            assert rc in (0, 4) and len(a) == sweeps
+            assert O.valid_tour(g) and O.tour_cost(c, g) == gcost
+            succ, cost = succ0.copy(), cost0
+            for i in range(sweeps):
+                dd, cost, mv = O.two_opt_once(c, succ, cost)
+                if dd < -1e-7:
+                    assert (a[i], b[i], d[i]) == (mv[0], mv[1], dd), i
+            assert np.array_equal(g, succ) and gcost == cost
+
+        e.set_option(96, 4)                                      # the 2nd .. 5th launch fail: more than the 3 retries
+        g = succ0.copy()
+        gcost, sweeps, rc = e.two_opt(g, time_left_s=0.003)     # first launch: a budget of a third of the time left
+        info = e.info()
+        assert info["persist_handed"] == 1 and info["stream_persist"] == 0 and sweeps > 20, (info, sweeps)
+        check(g, gcost, sweeps, rc)
+        e.set_option(96, 0)
+        # a first launch without its rendezvous (n = 5600: the default path is k_str2opt): nothing was touched, the per-sweep
+        # kernels run the descent, and the next descents keep to them (back-off) until the option re-arms the kernel
+        e.set_option(T.OPT_HISTORY, 0)
+        e.set_option(T.OPT_ELEM, 0); e.set_option(T.OPT_STREAM_PERSIST, 1); e.set_option(T.OPT_PERSIST, 1)
+        n2 = 5600
+        xy2 = O.random_points(n2, 5)
+        c2 = O.cost_matrix(xy2)
+        e.set_points(xy2); e.build_costs()
+        s2, cost2 = O.nn_tour(c2, 1)
+        e.set_option(97, -5000)
+        try:
+            sw = _descent_against_oracle(e, O, c2, s2, cost2, 12)
+            assert sw == 12 and e.info()["stream_persist"] == 0 and e.info()["persist"] == 0
+        finally:
+            e.set_option(97, 0)                                  # (also re-arms the one-launch kernels)
+        sw = _descent_against_oracle(e, O, c2, s2, cost2, 12)
+        assert sw == 12 and e.info()["stream_persist"] == 1
+    finally:
+        e.close()
 
 
 def test_lds_resident_hands_over_mid_descent(T, O, instances, golden):
