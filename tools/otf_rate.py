@@ -21,6 +21,12 @@ for mf in (1, 0):
         eng.tour_nn(0, 0)
         reps = 20 if n < 20000 else 3
         ms = eng.time_sweep(0, reps)
+        abl = {}
+        if mf == 1 and os.environ.get("OTF_ABLATE"):
+            for a in (3, 4, 5, 6):
+                eng.set_option(99, a); abl[a] = round(eng.time_sweep(0, reps) * 1e3, 1)
+            eng.set_option(99, 0)
+            print("  option 99 (3: early-out off, 4: nothing behind the box tests, 5: nothing behind the pair tests, 6: nothing behind the run-level box test) us/sweep:", abl, flush=True)
         i = eng.info()
         print(f"{what} n={n} matrix_free={i['matrix_free']} kernel={i['kernel']} elem={i['elem']} wgs={i['wgs_per_tour']}: "
               f"{ms*1e3:10.1f} us / sweep  {T.evals_per_sweep(n)/ms/1e6:8.1f} Gevals/s", flush=True)

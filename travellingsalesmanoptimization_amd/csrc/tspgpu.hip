@@ -2557,11 +2557,15 @@ __global__ void __launch_bounds__(256) k_gather_ispts(Tours S, int n, int slot0,
 // Per pair that leaves the two weights and three integer instructions.
 // ---------------------------------------------------------------------------
 constexpr int OTF8_RUN = 16;        // tour edges per workgroup: the per-b arrays (36 bytes per b) are streamed once per RUN pairs
-template <int KIND, bool TABU>
+constexpr int OTF8_RUN_INT = 64;    // ... with integer points (KIND_CEIL_INT): behind the early-out the sweep is bound by streaming the per-b
+                                    // arrays through the CU's load path (20 bytes per b and workgroup: 1.5 ms of a 1.7 ms sweep with runs of 16)
+template <int KIND, bool TABU, bool EARLY = false>
 __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
 {
     // 4 b's per thread with double2 points (8 need > 128 registers: two waves per SIMD only); 8 with int2 points
-    constexpr int RUN = OTF8_RUN, VB = KIND == KIND_CEIL_INT ? 8 : 4, VSH = KIND == KIND_CEIL_INT ? 3 : 2;
+    // (runs of 64 edges behind the early-out, where streaming the per-b arrays is what is left; the full evaluation of every
+    // pair -- tabu, the diagnostic build -- is fastest with 16: 3.9 vs 5.0 ms per sweep on pla85900)
+    constexpr int RUN = (KIND == KIND_CEIL_INT && !TABU && EARLY) ? OTF8_RUN_INT : OTF8_RUN, VB = KIND == KIND_CEIL_INT ? 8 : 4, VSH = KIND == KIND_CEIL_INT ? 3 : 2;
     __shared__ int nodes_s[RUN + 2];
     // CEIL_2D on integer coordinates: the points as int2 and the weight without f64 (edge_w_ceil_i)
     constexpr bool IPT = KIND == KIND_CEIL_INT;
@@ -2605,6 +2609,20 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     long long best_k = TABU ? 0x7fffffffffffffffll : 0ll;   // (delta << 34 | min(a,b) << 17 | max(a,b)); 0 = no improving move
     const int wave_lane0 = __builtin_amdgcn_readfirstlane(tid & ~63);
     const int NB = (n + 64 * VB - 1) / (64 * VB);
+    // the run's own boxes (see the early-out below): its a's, their successors, and the largest threshold of its steps
+    int rax0 = 0, rax1 = 0, ray0 = 0, ray1 = 0, rsx0 = 0, rsx1 = 0, rsy0 = 0, rsy1 = 0;
+    float ta2run = -1.0f;
+    if constexpr (IPT && !TABU && EARLY) {
+        rax0 = rax1 = npt[0].x; ray0 = ray1 = npt[0].y; rsx0 = rsx1 = npt[1].x; rsy0 = rsy1 = npt[1].y;
+        for (int s = 0; s < cnt; s++) {
+            const int2 pa = npt[s], ps = npt[s + 1];
+            rax0 = min(rax0, pa.x); rax1 = max(rax1, pa.x); ray0 = min(ray0, pa.y); ray1 = max(ray1, pa.y);
+            rsx0 = min(rsx0, ps.x); rsx1 = max(rsx1, ps.x); rsy0 = min(rsy0, ps.y); rsy1 = max(rsy1, ps.y);
+            const int da = dstep[s];
+            const float tq = (float)(da - 1);
+            ta2run = fmaxf(ta2run, da > 0 ? tq * tq * 1.000002f : -1.0f);
+        }
+    }
 
     for (int base = 0; base < n; base += BT * VB) {
         const int w0 = base + wave_lane0 * VB;           // this wave's first b
@@ -2622,9 +2640,40 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
             if constexpr (TABU)
                 if (is_tabu(A.tabu_list, bb, iter, tenure) || is_tabu(A.tabu_list, succ[bb], iter, tenure)) skm |= 1u << v;
         }
-        const int blkb = w0 / (64 * VB);
+        // Exact early-out (plain 2-opt, integer ceil-sqrt weights): delta = [w(a,b) - w(a,sa)] + [w(sa,sb) - w(b,sb)] < 0 needs one
+        // bracket negative, and a weight is a monotone function of the squared distance: w(a,b) < w(a,sa) implies
+        // d2(a,b) <= (w(a,sa) - 1)^2, w(sa,sb) < w(b,sb) implies d2(sa,sb) <= (w(b,sb) - 1)^2.  A wave-step none of whose 64 x VB
+        // pairs passes either test holds no improving pair and skips the two roots and the remainders; the f32 squared
+        // distances (relative error 2^-23; the thresholds carry a 2^-19 margin) are the ones the weights start from anyway.
+        // Same argmin: only pairs with delta >= 0 are left out, and those can never be chosen (refinment.c:63, :74).
+        // In front of the per-pair tests, per thread and step: the same two tests against the BOUNDING BOXES of the thread's VB b's and
+        // of their successors (a lower bound of every pair's squared distance against the largest threshold) -- consecutive node
+        // indices are neighbours in most instance files, so one box test stands for VB pair tests.
+        constexpr bool BOUND = IPT && !TABU && EARLY;
+        float tb2[BOUND ? VB : 1], tb2max = -1.0f;
+        int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;
+        if constexpr (BOUND) {
+            bx0 = bx1 = pb[0].x; by0 = by1 = pb[0].y; sx0 = sx1 = sp[0].x; sy0 = sy1 = sp[0].y;
 #pragma unroll
-        for (int s = 0; s < RUN; s++) {
+            for (int v = 0; v < VB; v++) {
+                const float tq = (float)(dn[v] - 1);
+                tb2[v] = dn[v] > 0 ? tq * tq * 1.000002f : -1.0f;
+                tb2max = fmaxf(tb2max, tb2[v]);
+                bx0 = min(bx0, pb[v].x); bx1 = max(bx1, pb[v].x); by0 = min(by0, pb[v].y); by1 = max(by1, pb[v].y);
+                sx0 = min(sx0, sp[v].x); sx1 = max(sx1, sp[v].x); sy0 = min(sy0, sp[v].y); sy1 = max(sy1, sp[v].y);
+            }
+            // ... and the whole run at once: the b box against the box of the run's a's under its largest threshold, the
+            // successor box against the box of the run's successors: a chunk far from the run skips its RUN steps together
+            {
+                const float ax = (float)max(max(bx0 - rax1, rax0 - bx1), 0), ay = (float)max(max(by0 - ray1, ray0 - by1), 0);
+                const float ux = (float)max(max(sx0 - rsx1, rsx0 - sx1), 0), uy = (float)max(max(sy0 - rsy1, rsy0 - sy1), 0);
+                const bool maybe = (__builtin_fmaf(ay, ay, ax * ax) <= ta2run) | (__builtin_fmaf(uy, uy, ux * ux) <= tb2max);
+                if (!__ballot(maybe) || A.ablate == 6) continue;
+            }
+        }
+        const int blkb = w0 / (64 * VB);
+#pragma unroll 16
+        for (int s = 0; s < RUN; s++) {               // (RUN = 16: fully unrolled)
             if (s >= cnt) break;
             const int a_raw = __builtin_amdgcn_readfirstlane(nodes[s]), sa_raw = __builtin_amdgcn_readfirstlane(nodes[s + 1]);
             if constexpr (TABU) { if ((a_raw | sa_raw) & TABU_NODE) continue; }
@@ -2637,11 +2686,34 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
             const bool hit = TABU && ((unsigned)(am - w0) < (unsigned)(64 * VB) || (unsigned)(sa - w0) < (unsigned)(64 * VB));
             const bool clean = !self && !hit && w0 + 64 * VB <= n;
             const PT pa = npt[s], ps = npt[s + 1];
+            unsigned vmask = (1u << VB) - 1u;               // slots v some lane of which may hold an improving pair
+            if constexpr (BOUND) {
+                const int da = dstep[s];
+                const float tq = (float)(da - 1), ta2 = da > 0 ? tq * tq * 1.000002f : -1.0f;
+                {
+                    {   // boxes first
+                        const float ax = (float)max(max(bx0 - pa.x, pa.x - bx1), 0), ay = (float)max(max(by0 - pa.y, pa.y - by1), 0);
+                        const float ux = (float)max(max(sx0 - ps.x, ps.x - sx1), 0), uy = (float)max(max(sy0 - ps.y, ps.y - sy1), 0);
+                        const bool maybe = (__builtin_fmaf(ay, ay, ax * ax) <= ta2) | (__builtin_fmaf(uy, uy, ux * ux) <= tb2max);
+                        if (!__ballot(maybe) || A.ablate == 4) continue;      // (4, 5: diagnostics -- nothing behind the box / pair tests)
+                    }
+                    vmask = 0;
+#pragma unroll
+                    for (int v = 0; v < VB; v++) {
+                        const float fx = (float)(pb[v].x - pa.x), fy = (float)(pb[v].y - pa.y);
+                        const float gx = (float)(sp[v].x - ps.x), gy = (float)(sp[v].y - ps.y);
+                        const bool pass = (__builtin_fmaf(fy, fy, fx * fx) <= ta2) | (__builtin_fmaf(gy, gy, gx * gx) <= tb2[v]);
+                        vmask |= __ballot(pass) ? 1u << v : 0u;
+                    }
+                    if (!vmask || A.ablate == 5) continue;
+                }
+            }
             auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
                 constexpr bool CHECK = decltype(check_tag)::value;
                 int m = 0x7fffffff;
 #pragma unroll
                 for (int v = 0; v < VB; v++) {
+                    if constexpr (BOUND) { if (!((vmask >> v) & 1u)) continue; }    // (wave-uniform)
                     int dl = weight(pa, pb[v]) + weight(ps, sp[v]) - dn[v];
                     if constexpr (CHECK) {
                         const int b = b0 + v;
@@ -2651,6 +2723,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
                     if constexpr (TABU) dl = ((skm >> v) & 1u) ? MASKED32 : dl;
                     m = min(m, (dl << VSH) | v);
                 }
+                if (m == 0x7fffffff) return;                  // (every slot filtered out in every lane... cannot happen with vmask != 0)
                 const int b = b0 + (m & (VB - 1));
                 const long long key = ((long long)((m >> VSH) - dstep[s]) << 34) | ((long long)min(a, b) << 17) | (long long)max(a, b);
                 best_k = key < best_k ? key : best_k;
@@ -3092,6 +3165,7 @@ struct tspgpu_ctx {
     bool sp_used = false;      // the last descent ran in k_str2opt
     bool sp_attr[4] = {false, false, false, false};
     int opt_sp_nch = 0;        // probe hook 93
+    bool plan_otf_early = false;   // the matrix-free plan is the early-out kernel's (runs of 64 edges: plain 2-opt over integer points)
     bool lp_attr[6] = {false, false, false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
     bool max8k = false;        // ... <= 8190 (the tabu form of the packed loop: a poisoned pair must exceed every valid delta)
@@ -3425,7 +3499,7 @@ static int make_plan(tspgpu_ctx *ctx, int ntours)
             HIP_TRY(hipMalloc(&ctx->d_spts, (size_t)ntours * n * sizeof(double2)));
             ctx->spts_cap = (size_t)ntours * n;
         }
-        P = (ctx->cost_bound < 33554432.0 && n < 131072) ? OTF8_RUN : 8;     // (k_sweep_otf8 / k_sweep_otf: see launch_sweep)
+        P = (ctx->cost_bound < 33554432.0 && n < 131072) ? (ctx->plan_otf_early ? OTF8_RUN_INT : OTF8_RUN) : 8;     // (k_sweep_otf8 / k_sweep_otf: see launch_sweep)
         G = (n + P - 1) / P;
         if (G > ctx->S.pstride) return fail(ctx, E_INTERNAL, "partial stride %d < %d workgroups", ctx->S.pstride, G);
         ctx->plan_kernel = 4; ctx->plan_G = G; ctx->plan_P = P; ctx->plan_BT = 256; ctx->plan_NCH = 0; ctx->plan_D = 0;
@@ -3575,8 +3649,11 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
         if (ctx->cost_bound < 33554432.0 && n < 131072) {     // 2^25, 17-bit labels
             const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
 #define OTF8(K) (tabu ? (const void *)k_sweep_otf8<K, true> : (const void *)k_sweep_otf8<K, false>)
+            // plain 2-opt over integer points: with the exact early-out (option 99 = 3: without it, the full evaluation of every
+            // pair -- diagnostics, tools/otf_rate.py)
             fo = kind == TSPGPU_EUC_2D ? OTF8(TSPGPU_EUC_2D) : kind == TSPGPU_ATT ? OTF8(TSPGPU_ATT)
-               : kind == KIND_CEIL_INT ? OTF8(KIND_CEIL_INT) : OTF8(TSPGPU_CEIL_2D);
+               : kind == KIND_CEIL_INT ? (!tabu && ctx->plan_otf_early ? (const void *)k_sweep_otf8<KIND_CEIL_INT, false, true> : OTF8(KIND_CEIL_INT))
+               : OTF8(TSPGPU_CEIL_2D);
 #undef OTF8
         }
         void *ao[] = {&A};
@@ -4204,6 +4281,25 @@ __global__ void k_rebase(Tours S, int slot, int delta)     // sweep counter and 
 
 static int run_sweeps_plain(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long max_iters, double time_left_s, bool *deadline_hit);
 
+// the launch plan for `ntours` tours in flight, plain 2-opt or tabu: the matrix-free sweep over integer points runs two
+// instantiations with different run lengths (early-out: 64 edges per workgroup; full evaluation: 16), so the number of
+// partials a sweep leaves -- what k_apply reduces -- follows the variant
+static bool otf_early(const tspgpu_ctx *ctx, bool tabu)
+{
+    return ctx->otf && !tabu && ctx->opt_ablate != 3 && ctx->ceil_int() && ctx->d_ipts && ctx->cost_bound < 33554432.0 && ctx->n < 131072;
+}
+static int ensure_plan(tspgpu_ctx *ctx, int ntours, bool tabu)
+{
+    const bool early = otf_early(ctx, tabu);
+    if (ctx->plan_T != ntours || ctx->plan_kernel == 0 || (ctx->otf && ctx->plan_otf_early != early)) {
+        ctx->plan_otf_early = early;
+        int rc = make_plan(ctx, ntours);
+        if (rc) return rc;
+        drop_graphs(ctx);
+    }
+    return E_OK;
+}
+
 // A one-launch descent began and lost its grid (another context took CUs): the slot holds the tour its last completed
 // launch wrote back.  The per-sweep kernels count their sweeps from 0: run them on a rebased counter / cap / history and shift
 // everything back afterwards.
@@ -4229,10 +4325,9 @@ static int run_sweeps(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, long ma
                       bool *deadline_hit)
 {
     if (deadline_hit) *deadline_hit = false;
-    if (ctx->plan_T != ntours || ctx->plan_kernel == 0) {
-        int rc = make_plan(ctx, ntours);
+    {
+        const int rc = ensure_plan(ctx, ntours, tabu);
         if (rc) return rc;
-        drop_graphs(ctx);
     }
     // One launch per sweep pays in the latency-bound regime (a few tours in flight: the apply
     // launch is ~30 % of an iteration); in a large batch the separate apply launch serves every
@@ -5307,7 +5402,7 @@ int tspgpu_tour_sweep_part(tspgpu_ctx *ctx, int slot, int part, int nparts, doub
     if (rc) return rc;
     if ((rc = need_slot(ctx, slot))) return rc;
     if (!ctx->symmetric) return fail(ctx, E_PRECOND, "a sharded sweep needs a symmetric matrix (both orientations of a pair live in different parts otherwise)");
-    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    if ((rc = ensure_plan(ctx, 1, false))) return rc;
     const int G = ctx->plan_G;
     const int g_lo = (int)((long)part * G / nparts), g_hi = (int)((long)(part + 1) * G / nparts);
     *delta = 0.0; *a = 0; *b = 0;
@@ -5334,7 +5429,7 @@ int tspgpu_tour_apply_move(tspgpu_ctx *ctx, int slot, int a, int b, double delta
     int rc = need_costs(ctx);
     if (rc) return rc;
     if ((rc = need_slot(ctx, slot))) return rc;
-    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    if ((rc = ensure_plan(ctx, 1, false))) return rc;
     const int G = ctx->plan_G;
     const u64 key = delta < TWO_OPT_EPS ? (a < b ? ((u64)(unsigned)a << 32) | (unsigned)b : ((u64)(unsigned)b << 32) | (unsigned)a) : 0;
     hipLaunchKernelGGL(k_set_move, dim3((G + 255) / 256), dim3(256), 0, ctx->stream, ctx->S, slot, G, delta < TWO_OPT_EPS ? delta : 0.0, key);
@@ -5351,7 +5446,7 @@ int tspgpu_time_sweep(tspgpu_ctx *ctx, int slot, int reps, float *ms_mean)
     int rc = need_costs(ctx);
     if (rc) return rc;
     if ((rc = need_slot(ctx, slot))) return rc;
-    if (ctx->plan_T != 1 || ctx->plan_kernel == 0) { if ((rc = make_plan(ctx, 1))) return rc; drop_graphs(ctx); }
+    if ((rc = ensure_plan(ctx, 1, false))) return rc;
     hipLaunchKernelGGL(k_rearm, dim3(1), dim3(64), 0, ctx->stream, ctx->S, slot, 1, -1);
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
