@@ -983,12 +983,16 @@ def test_vns_with_host_kicks(eng, T, O, instances, golden):
 
 
 # ------------------------------------------------------------------ matrix-free mode
-@pytest.fixture
-def mf(eng, T):
+@pytest.fixture(params=[0, 1], ids=["auto", "early_out"])
+def mf(eng, T, request):
+    """matrix-free engine; "early_out": hook 91 forces the exact early-out kernel (k_sweep_otf8<., false, true>: runs of 64
+    edges, run- / thread- / pair-level squared-distance tests in front of the weights) onto every size and weight kind --
+    by default it runs for integer points and n >= 128 x CUs only (pla85900)"""
     eng.set_option(T.OPT_MATRIX_FREE, 1)
     eng.set_option(T.OPT_ELEM, 0); eng.set_option(T.OPT_KERNEL, 0)
+    eng.set_option(91, request.param)
     yield eng
-    eng.set_option(T.OPT_MATRIX_FREE, 0)
+    eng.set_option(T.OPT_MATRIX_FREE, 0); eng.set_option(91, 0)
 
 
 @pytest.mark.parametrize("name", ["berlin52", "eil51", "kroA100", "pr1002", "n1000_s123"])
@@ -2049,12 +2053,13 @@ def test_random_configurations_against_the_oracle(eng, T, O, seed):
     window = int(r.choice([0, 1, 2]))
     stream = int(r.choice([1, 1, 2])) if n >= 1024 else 1
     mfree = int(r.choice([2, 2, 1])) if xy is not None else 2
+    early = int(r.choice([0, 1, 2]))
     opts = dict(n=n, kind=kind, elem=elem, kernel=kernel, fused=fused, persist=persist, window=window, stream=stream, mfree=mfree,
-                matrix=xy is None)
+                early=early, matrix=xy is None)
     try:
         eng.set_option(T.OPT_ELEM, elem); eng.set_option(T.OPT_KERNEL, kernel); eng.set_option(T.OPT_FUSED, fused)
         eng.set_option(T.OPT_PERSIST, persist); eng.set_option(T.OPT_PERSIST_WINDOW, window); eng.set_option(T.OPT_STREAM_PERSIST, stream)
-        eng.set_option(T.OPT_MATRIX_FREE, mfree)
+        eng.set_option(T.OPT_MATRIX_FREE, mfree); eng.set_option(91, early)
         eng.set_option(T.OPT_PERSIST_EDGES, int(r.choice([0, 0, 3, 7])))
         if xy is not None:
             eng.set_points(xy, kind); eng.build_costs()
@@ -2080,7 +2085,7 @@ def test_random_configurations_against_the_oracle(eng, T, O, seed):
         raise AssertionError(f"{opts}: {e}") from e
     finally:
         for o, v in ((T.OPT_ELEM, 0), (T.OPT_KERNEL, 0), (T.OPT_FUSED, 1), (T.OPT_PERSIST, 1), (T.OPT_PERSIST_WINDOW, 0),
-                     (T.OPT_STREAM_PERSIST, 1), (T.OPT_MATRIX_FREE, 0), (T.OPT_PERSIST_EDGES, 0)):
+                     (T.OPT_STREAM_PERSIST, 1), (T.OPT_MATRIX_FREE, 0), (T.OPT_PERSIST_EDGES, 0), (91, 0)):
             eng.set_option(o, v)
 
 

@@ -9,6 +9,9 @@ from bench import reference_points
 what = sys.argv[1] if len(sys.argv) > 1 else "pla85900"
 if what.startswith("n") and what[1:].isdigit():
     xy, kind = reference_points(int(what[1:]), 123), T.EUC_2D
+elif what.startswith("r") and what[1:].isdigit():          # uniform-random INTEGER points, CEIL_2D: pla85900's weight kind without its node order
+    import numpy as np
+    xy, kind = np.random.RandomState(5).randint(0, 1400000, size=(int(what[1:]), 2)).astype(np.float64), T.CEIL_2D
 else:
     xy, kind = tsplib.read(os.path.join(ROOT, "tests", "golden", "data", what + ".tsp"))
 n = len(xy)

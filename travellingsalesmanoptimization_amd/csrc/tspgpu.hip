@@ -2565,7 +2565,7 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     // 4 b's per thread with double2 points (8 need > 128 registers: two waves per SIMD only); 8 with int2 points
     // (runs of 64 edges behind the early-out, where streaming the per-b arrays is what is left; the full evaluation of every
     // pair -- tabu, the diagnostic build -- is fastest with 16: 3.9 vs 5.0 ms per sweep on pla85900)
-    constexpr int RUN = (KIND == KIND_CEIL_INT && !TABU && EARLY) ? OTF8_RUN_INT : OTF8_RUN, VB = KIND == KIND_CEIL_INT ? 8 : 4, VSH = KIND == KIND_CEIL_INT ? 3 : 2;
+    constexpr int RUN = (!TABU && EARLY) ? OTF8_RUN_INT : OTF8_RUN, VB = KIND == KIND_CEIL_INT ? 8 : 4, VSH = KIND == KIND_CEIL_INT ? 3 : 2;
     __shared__ int nodes_s[RUN + 2];
     // CEIL_2D on integer coordinates: the points as int2 and the weight without f64 (edge_w_ceil_i)
     constexpr bool IPT = KIND == KIND_CEIL_INT;
@@ -2610,17 +2610,29 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
     const int wave_lane0 = __builtin_amdgcn_readfirstlane(tid & ~63);
     const int NB = (n + 64 * VB - 1) / (64 * VB);
     // the run's own boxes (see the early-out below): its a's, their successors, and the largest threshold of its steps
-    int rax0 = 0, rax1 = 0, ray0 = 0, ray1 = 0, rsx0 = 0, rsx1 = 0, rsy0 = 0, rsy1 = 0;
+    typedef typename std::conditional<IPT, int, double>::type CT;      // coordinate type
+    constexpr bool BOUND = !TABU && EARLY;
+    // threshold of an edge (u, v) of weight w: a pair can only improve if one of its new edges is shorter than the old edge it is
+    // bracketed with.  Integer ceil-sqrt weights: shorter means weight <= w - 1, i.e. squared distance <= (w - 1)^2; the other kinds:
+    // a weight is a monotone function of the squared distance as the kernels compute it, so shorter needs a smaller squared
+    // distance.  f32 with a 2^-18 margin (the tests below lose at most 2^-22).
+    auto thr = [](const PT &u, const PT &v, int w) __attribute__((always_inline)) {
+        if constexpr (IPT) { const float tq = (float)(w - 1); return w > 0 ? tq * tq * 1.000004f : -1.0f; }
+        else { const double dx = v.x - u.x, dy = v.y - u.y; return (float)(dx * dx + dy * dy) * 1.000004f; }
+    };
+    auto gap = [](CT lo, CT hi, CT qlo, CT qhi) __attribute__((always_inline)) {      // distance between the intervals [lo, hi] and [qlo, qhi]
+        if constexpr (IPT) return (float)max(max(lo - qhi, qlo - hi), 0);
+        else return (float)fmax(fmax(lo - qhi, qlo - hi), 0.0);
+    };
+    CT rax0 = 0, rax1 = 0, ray0 = 0, ray1 = 0, rsx0 = 0, rsx1 = 0, rsy0 = 0, rsy1 = 0;
     float ta2run = -1.0f;
-    if constexpr (IPT && !TABU && EARLY) {
+    if constexpr (BOUND) {
         rax0 = rax1 = npt[0].x; ray0 = ray1 = npt[0].y; rsx0 = rsx1 = npt[1].x; rsy0 = rsy1 = npt[1].y;
         for (int s = 0; s < cnt; s++) {
-            const int2 pa = npt[s], ps = npt[s + 1];
+            const PT pa = npt[s], ps = npt[s + 1];
             rax0 = min(rax0, pa.x); rax1 = max(rax1, pa.x); ray0 = min(ray0, pa.y); ray1 = max(ray1, pa.y);
             rsx0 = min(rsx0, ps.x); rsx1 = max(rsx1, ps.x); rsy0 = min(rsy0, ps.y); rsy1 = max(rsy1, ps.y);
-            const int da = dstep[s];
-            const float tq = (float)(da - 1);
-            ta2run = fmaxf(ta2run, da > 0 ? tq * tq * 1.000002f : -1.0f);
+            ta2run = fmaxf(ta2run, thr(pa, ps, dstep[s]));
         }
     }
 
@@ -2649,15 +2661,13 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
         // In front of the per-pair tests, per thread and step: the same two tests against the BOUNDING BOXES of the thread's VB b's and
         // of their successors (a lower bound of every pair's squared distance against the largest threshold) -- consecutive node
         // indices are neighbours in most instance files, so one box test stands for VB pair tests.
-        constexpr bool BOUND = IPT && !TABU && EARLY;
         float tb2[BOUND ? VB : 1], tb2max = -1.0f;
-        int bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;
+        CT bx0 = 0, bx1 = 0, by0 = 0, by1 = 0, sx0 = 0, sx1 = 0, sy0 = 0, sy1 = 0;
         if constexpr (BOUND) {
             bx0 = bx1 = pb[0].x; by0 = by1 = pb[0].y; sx0 = sx1 = sp[0].x; sy0 = sy1 = sp[0].y;
 #pragma unroll
             for (int v = 0; v < VB; v++) {
-                const float tq = (float)(dn[v] - 1);
-                tb2[v] = dn[v] > 0 ? tq * tq * 1.000002f : -1.0f;
+                tb2[v] = thr(pb[v], sp[v], dn[v]);
                 tb2max = fmaxf(tb2max, tb2[v]);
                 bx0 = min(bx0, pb[v].x); bx1 = max(bx1, pb[v].x); by0 = min(by0, pb[v].y); by1 = max(by1, pb[v].y);
                 sx0 = min(sx0, sp[v].x); sx1 = max(sx1, sp[v].x); sy0 = min(sy0, sp[v].y); sy1 = max(sy1, sp[v].y);
@@ -2665,8 +2675,8 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
             // ... and the whole run at once: the b box against the box of the run's a's under its largest threshold, the
             // successor box against the box of the run's successors: a chunk far from the run skips its RUN steps together
             {
-                const float ax = (float)max(max(bx0 - rax1, rax0 - bx1), 0), ay = (float)max(max(by0 - ray1, ray0 - by1), 0);
-                const float ux = (float)max(max(sx0 - rsx1, rsx0 - sx1), 0), uy = (float)max(max(sy0 - rsy1, rsy0 - sy1), 0);
+                const float ax = gap(bx0, bx1, rax0, rax1), ay = gap(by0, by1, ray0, ray1);
+                const float ux = gap(sx0, sx1, rsx0, rsx1), uy = gap(sy0, sy1, rsy0, rsy1);
                 const bool maybe = (__builtin_fmaf(ay, ay, ax * ax) <= ta2run) | (__builtin_fmaf(uy, uy, ux * ux) <= tb2max);
                 if (!__ballot(maybe) || A.ablate == 6) continue;
             }
@@ -2688,25 +2698,22 @@ __global__ void __launch_bounds__(256) k_sweep_otf8(SweepArgs A)
             const PT pa = npt[s], ps = npt[s + 1];
             unsigned vmask = (1u << VB) - 1u;               // slots v some lane of which may hold an improving pair
             if constexpr (BOUND) {
-                const int da = dstep[s];
-                const float tq = (float)(da - 1), ta2 = da > 0 ? tq * tq * 1.000002f : -1.0f;
-                {
-                    {   // boxes first
-                        const float ax = (float)max(max(bx0 - pa.x, pa.x - bx1), 0), ay = (float)max(max(by0 - pa.y, pa.y - by1), 0);
-                        const float ux = (float)max(max(sx0 - ps.x, ps.x - sx1), 0), uy = (float)max(max(sy0 - ps.y, ps.y - sy1), 0);
-                        const bool maybe = (__builtin_fmaf(ay, ay, ax * ax) <= ta2) | (__builtin_fmaf(uy, uy, ux * ux) <= tb2max);
-                        if (!__ballot(maybe) || A.ablate == 4) continue;      // (4, 5: diagnostics -- nothing behind the box / pair tests)
-                    }
-                    vmask = 0;
-#pragma unroll
-                    for (int v = 0; v < VB; v++) {
-                        const float fx = (float)(pb[v].x - pa.x), fy = (float)(pb[v].y - pa.y);
-                        const float gx = (float)(sp[v].x - ps.x), gy = (float)(sp[v].y - ps.y);
-                        const bool pass = (__builtin_fmaf(fy, fy, fx * fx) <= ta2) | (__builtin_fmaf(gy, gy, gx * gx) <= tb2[v]);
-                        vmask |= __ballot(pass) ? 1u << v : 0u;
-                    }
-                    if (!vmask || A.ablate == 5) continue;
+                const float ta2 = thr(pa, ps, dstep[s]);
+                {   // boxes first
+                    const float ax = gap(bx0, bx1, pa.x, pa.x), ay = gap(by0, by1, pa.y, pa.y);
+                    const float ux = gap(sx0, sx1, ps.x, ps.x), uy = gap(sy0, sy1, ps.y, ps.y);
+                    const bool maybe = (__builtin_fmaf(ay, ay, ax * ax) <= ta2) | (__builtin_fmaf(uy, uy, ux * ux) <= tb2max);
+                    if (!__ballot(maybe) || A.ablate == 4) continue;      // (4, 5, 6: diagnostics -- nothing behind the box / pair / run tests)
                 }
+                vmask = 0;
+#pragma unroll
+                for (int v = 0; v < VB; v++) {
+                    const float fx = (float)(pb[v].x - pa.x), fy = (float)(pb[v].y - pa.y);
+                    const float gx = (float)(sp[v].x - ps.x), gy = (float)(sp[v].y - ps.y);
+                    const bool pass = (__builtin_fmaf(fy, fy, fx * fx) <= ta2) | (__builtin_fmaf(gy, gy, gx * gx) <= tb2[v]);
+                    vmask |= __ballot(pass) ? 1u << v : 0u;
+                }
+                if (!vmask || A.ablate == 5) continue;
             }
             auto pairs = [&](auto check_tag) __attribute__((always_inline)) {
                 constexpr bool CHECK = decltype(check_tag)::value;
@@ -3165,6 +3172,7 @@ struct tspgpu_ctx {
     bool sp_used = false;      // the last descent ran in k_str2opt
     bool sp_attr[4] = {false, false, false, false};
     int opt_sp_nch = 0;        // probe hook 93
+    int opt_otf_early = 0;         // hook 91: 0 automatic, 1 the early-out kernel for every matrix-free sweep, 2 never
     bool plan_otf_early = false;   // the matrix-free plan is the early-out kernel's (runs of 64 edges: plain 2-opt over integer points)
     bool lp_attr[6] = {false, false, false, false, false, false};
     bool max16k = false;       // every off-diagonal cell <= 16383 (packed 16-bit deltas cannot overflow)
@@ -3648,12 +3656,11 @@ static int launch_sweep(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, int g
         const void *fo = tabu ? (const void *)k_sweep_otf<true> : (const void *)k_sweep_otf<false>;
         if (ctx->cost_bound < 33554432.0 && n < 131072) {     // 2^25, 17-bit labels
             const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
-#define OTF8(K) (tabu ? (const void *)k_sweep_otf8<K, true> : (const void *)k_sweep_otf8<K, false>)
-            // plain 2-opt over integer points: with the exact early-out (option 99 = 3: without it, the full evaluation of every
+#define OTF8(K) (tabu ? (const void *)k_sweep_otf8<K, true> : ctx->plan_otf_early ? (const void *)k_sweep_otf8<K, false, true> : (const void *)k_sweep_otf8<K, false>)
+            // plain 2-opt: with the exact early-out and runs of 64 edges (option 99 = 3: without it, the full evaluation of every
             // pair -- diagnostics, tools/otf_rate.py)
             fo = kind == TSPGPU_EUC_2D ? OTF8(TSPGPU_EUC_2D) : kind == TSPGPU_ATT ? OTF8(TSPGPU_ATT)
-               : kind == KIND_CEIL_INT ? (!tabu && ctx->plan_otf_early ? (const void *)k_sweep_otf8<KIND_CEIL_INT, false, true> : OTF8(KIND_CEIL_INT))
-               : OTF8(TSPGPU_CEIL_2D);
+               : kind == KIND_CEIL_INT ? OTF8(KIND_CEIL_INT) : OTF8(TSPGPU_CEIL_2D);
 #undef OTF8
         }
         void *ao[] = {&A};
@@ -4286,7 +4293,13 @@ static int run_sweeps_plain(tspgpu_ctx *ctx, int slot0, int ntours, bool tabu, l
 // partials a sweep leaves -- what k_apply reduces -- follows the variant
 static bool otf_early(const tspgpu_ctx *ctx, bool tabu)
 {
-    return ctx->otf && !tabu && ctx->opt_ablate != 3 && ctx->ceil_int() && ctx->d_ipts && ctx->cost_bound < 33554432.0 && ctx->n < 131072;
+    if (!ctx->otf || tabu || ctx->opt_ablate == 3 || ctx->opt_otf_early == 2 || !(ctx->cost_bound < 33554432.0 && ctx->n < 131072)) return false;
+    if (ctx->opt_otf_early == 1) return true;          // (hook 91: every weight kind, every size -- tests)
+    // automatic: integer points (the tests are integer subtractions and f32 products) and enough 64-edge runs for two workgroups
+    // per CU.  Measured (tools/otf_rate.py): pla85900 3.94 -> 0.93 ms per sweep, 85 900 uniform-random integer points (no
+    // locality in the node order: only the pair tests reject) 4.01 -> 2.94; but n = 20 000 305 -> 360 us (313 workgroups), and
+    // with double points (f64 subtractions in every test) d18512 296 -> 322 us, n = 16 384 uniform 210 -> 345 us
+    return ctx->ceil_int() && ctx->d_ipts && ctx->n >= 128 * ctx->cus;
 }
 static int ensure_plan(tspgpu_ctx *ctx, int ntours, bool tabu)
 {
@@ -4766,6 +4779,7 @@ int tspgpu_set_option(tspgpu_ctx *ctx, int option, long value)
     case TSPGPU_OPT_BLOCK: if (value < 0 || value > 1024) return fail(ctx, E_INVALID, "bad block"); ctx->opt_block = (int)value; ctx->plan_kernel = 0; break;
     case TSPGPU_OPT_DEPTH: if (value < 0 || value > 8) return fail(ctx, E_INVALID, "bad depth"); ctx->opt_depth = (int)value; ctx->plan_kernel = 0; break;
     case 99: ctx->opt_ablate = (int)value; drop_graphs(ctx); break; // undocumented: kernel ablation for profiling
+    case 91: ctx->opt_otf_early = value == 1 || value == 2 ? (int)value : 0; ctx->plan_kernel = 0; drop_graphs(ctx); break; // undocumented: see otf_early()
     case 92: ctx->opt_build_tile = (int)value; break; // undocumented: tile of the triangle build (tools/build_probe.py)
     case 93: ctx->opt_sp_nch = value == 1 || value == 2 ? (int)value : 0; break; // undocumented: vectors per thread of k_str2opt (tools/stream_probe.py)
     case 94: ctx->opt_vns_launch_k = value > 0 ? (int)std::min<long>(value, 65536) : 65536; break; // undocumented: VNS iterations per launch (tests)
