@@ -877,6 +877,14 @@ def main():
                     row["stderr_tail"] = r.stderr[-300:]
                 out[key] = row
             out["pr1002_all_starts"]["golden_cost_266290"] = out["pr1002_all_starts"].get("stdout") == "Cost: 266290.00"   # whole stdout
+            # BASELINE config 5 as it is named, end to end through the reference's CLI with no time limit: pla85900, VNS, on-the-fly
+            # distances -- All-NN over the 85 900 starts, then 3 iterations of { 2-opt to the local optimum, kicks }
+            # (tests/test_host_c.py::test_config5_vns_pla85900_end_to_end_through_the_host_layer certifies the incumbent)
+            t1 = time.perf_counter()
+            r = subprocess.run([tsp, "-f", os.path.join(DATA, "pla85900.tsp"), "-alg", "VNS", "-k", "3", "-q"], capture_output=True, text=True,
+                               timeout=400, env=dict(env, TSP_ALLOW_EXT="1"), cwd=ROOT)
+            out["config5_pla85900_vns_k3"] = {"rc": r.returncode, "stdout": r.stdout.strip()[:80], "process_wall_s": time.perf_counter() - t1,
+                                              "what": "All-NN (85 900 NN tours) + 3 VNS iterations over on-the-fly distances, no -t"}
             return out
         host_c = guarded(host_c_leg)
 

@@ -213,6 +213,53 @@ def test_binary_vns_pla85900_honours_deadline():
 
 
 @pytest.mark.gpu
+def test_config5_vns_pla85900_end_to_end_through_the_host_layer(O, tmp_path):
+    """BASELINE config 5 as it is named -- pla85900.tsp, VNS (3-opt kick + GPU 2-opt), on-the-fly distances -- END TO END
+    through the reference's own entry point (tsp_run_algorithm -> mh_VNS, metaheuristic.c:251-341) with NO time limit: All-NN
+    over the 85 900 starts (h_Greedy_iterative, ~10 s), then k = 3 iterations of { ref_2opt to the local optimum, incumbent,
+    kicks on the program's glibc stream }.  Round 3 could only watch this run being cut inside All-NN by its deadline; with
+    the matrix-free early-out a descent takes ~3 s.  Checked: exit state T_OK, the incumbent is a valid tour whose cost is the
+    oracle's recomputation, no worse than the All-NN tour, and -- an incumbent of mh_VNS is always the result of a ref_2opt
+    -- a 2-opt LOCAL OPTIMUM by one full oracle sweep; and the `tsp` binary prints the same cost (deterministic: the
+    private glibc stream of a fresh process)."""
+    import numpy as np
+    out = str(tmp_path / "best.npy")
+    code = f"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {os.path.join(ROOT, "tests")!r})
+os.environ["TSP_ALLOW_EXT"] = "1"
+from test_host_c import Instance
+host = C.CDLL({os.path.join(HOST, "libtsphost.so")!r})
+argv = [b"tsp", b"-f", {os.path.join(DATA, "pla85900.tsp")!r}.encode(), b"-alg", b"VNS", b"-k", b"3", b"-q"]
+arr = (C.c_char_p * len(argv))(*argv)
+assert host.tsp_parse_commandline(len(argv), arr) == 0
+host.tsp_read_input()
+inst = Instance.in_dll(host, "tsp_inst")
+host.utils_startclock(C.byref(inst, Instance.c.offset))
+os.makedirs("results", exist_ok=True)
+rc = host.tsp_run_algorithm()
+n = inst.nnodes
+path = np.ctypeslib.as_array(inst.best_solution.path, shape=(n,)).copy()
+np.save({out!r}, path)
+print("RESULT", rc, n, repr(inst.best_solution.cost), bool(inst.costs))
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-500:], r.stderr[-2000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][0].split()
+    rc, n, cost, has_matrix = int(line[1]), int(line[2]), float(line[3]), line[4] == "True"
+    assert rc == 0 and n == 85900 and not has_matrix             # T_OK; no n x n matrix anywhere
+    path = np.load(out)
+    xy, ewt = O.read_tsplib(os.path.join(DATA, "pla85900.tsp"))
+    assert ewt == "CEIL_2D" and O.valid_tour(path) and O.tour_cost_xy(xy, O.CEIL_2D, path) == cost
+    assert cost < 162673661.0                                    # better than the best NN tour (All-NN: start 43632)
+    d, mv = O.two_opt_best_move_xy(xy, O.CEIL_2D, path, threads=16)
+    assert d >= -1e-7, (d, mv)                                   # a 2-opt local optimum by the reference's own scan
+    rc2, out2, err2 = run_q("-f", os.path.join(DATA, "pla85900.tsp"), "-alg", "VNS", "-k", "3", env={"TSP_ALLOW_EXT": "1"})
+    assert rc2 == 0 and out2 == "Cost: %.2f" % cost, (out2, err2[-500:])
+
+
+@pytest.mark.gpu
 def test_bench_line_contract():
     """bench.py prints ONE JSON line carrying the driver's contract fields, the roofline object and
     the parity gate (final cost of the headline workload)"""
