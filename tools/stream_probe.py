@@ -15,6 +15,8 @@ names = ["state+nodes", "stream+evaluate", "reduce+record", "exchange", "apply"]
 for n, nch in [(n, c) for n in sizes for c in NCHS]:
     eng = T.Engine(0)
     eng.set_option(93, nch)
+    if os.environ.get("SP_FORCE"):
+        eng.set_option(T.OPT_PERSIST, 0); eng.set_option(T.OPT_STREAM_PERSIST, 2)
     eng.set_points(reference_points(n, 123)); eng.build_costs()
     eng.tour_nn(0, 0)
     eng.tour_copy(1, 0); eng.tour_two_opt(1)

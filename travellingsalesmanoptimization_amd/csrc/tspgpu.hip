@@ -5321,7 +5321,13 @@ int tspgpu_nn_all_timed(tspgpu_ctx *ctx, const int *starts, int nstarts, double 
     if (rc) return rc;
     const double t0 = now_s();
     const double t_end = time_left_s >= 0 ? t0 + time_left_s : -1;
-    const int cap = std::min(nstarts, ctx->opt_max_tours);
+    // NN tours in flight: one wave per start, and a step is a dependent chain of ~1.3 us whatever else runs -- the chip takes
+    // 13-16 waves per CU (the visited bits of a tour in LDS) where the multi-start default of 1024 tours leaves 4: 4096 starts
+    // per launch while the slots stay below 12 GB and the caller has not set TSPGPU_OPT_MAX_TOURS itself
+    // (pla85900 All-NN, 85 900 tours: 10.5 -> 6.0 s)
+    int want = ctx->opt_max_tours;
+    if (want == 1024 && (size_t)4096 * 28 * (size_t)ctx->n <= ((size_t)12 << 30)) want = 4096;
+    const int cap = std::min(nstarts, want);
     if ((rc = ensure_tours(ctx, cap))) return rc;
     double best = DBL_MAX; int arg = -1;
     std::vector<int> hs(cap);
