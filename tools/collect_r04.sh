@@ -23,6 +23,7 @@ run trace_batch --kernel-trace --stats --output-format csv -d "$out/trace_batch"
 run trace_n5600 --kernel-trace --stats --output-format csv -d "$out/trace_n5600" -- python3 tools/run_instance.py 5600 3
 run trace_n8192 --kernel-trace --stats --output-format csv -d "$out/trace_n8192" -- python3 tools/run_instance.py 8192 3
 run trace_otf --kernel-trace --stats --output-format csv -d "$out/trace_otf" -- python3 tools/otf_rate.py pla85900
+OTF_FULL=1 run trace_otf_full --kernel-trace --stats --output-format csv -d "$out/trace_otf_full" -- python3 tools/otf_rate.py pla85900
 find "$out" -name "*_kernel_trace.csv" -delete
 run fetch_batch --pmc FETCH_SIZE --output-format csv -d "$out/fetch_batch" -- python3 tools/multistart_rate.py n4096 64
 run write_batch --pmc WRITE_SIZE --output-format csv -d "$out/write_batch" -- python3 tools/multistart_rate.py n4096 64

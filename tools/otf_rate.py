@@ -23,6 +23,8 @@ for mf in (1, 0):
         eng.build_costs()
         eng.tour_nn(0, 0)
         reps = 20 if n < 20000 else 3
+        if os.environ.get("OTF_FULL"):
+            eng.set_option(99, 3)                      # every pair evaluated in full (the early-out off)
         ms = eng.time_sweep(0, reps)
         abl = {}
         if mf == 1 and os.environ.get("OTF_ABLATE"):

@@ -8,10 +8,10 @@ root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles"
 shutil.copy(os.path.join(src, "bench_default.json"), os.path.join(root, "r04_bench_default.json"))
 for tag, dst in (("n4096", "r04_kernel_stats_n4096_lds.csv"), ("batch", "r04_kernel_stats_n4096_batch64.csv"),
                  ("n5600", "r04_kernel_stats_n5600_stream.csv"), ("n8192", "r04_kernel_stats_n8192_stream.csv"),
-                 ("otf", "r04_kernel_stats_pla85900_otf.csv")):
-    st = glob.glob(os.path.join(src, f"trace_{tag}", "*", "*_kernel_stats.csv"))
+                 ("otf", "r04_kernel_stats_pla85900_otf.csv"), ("otf_full", "r04_kernel_stats_pla85900_otf_full_evaluation.csv")):
+    st = sorted(glob.glob(os.path.join(src, f"trace_{tag}", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
     if st:
-        shutil.copy(st[0], os.path.join(root, dst))
+        shutil.copy(st[-1], os.path.join(root, dst))
 tpath = os.path.join(root, "traffic.json")
 traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
 lines = ["workload,kernel,counter,launches,mean_bytes_per_launch,total_bytes"]
