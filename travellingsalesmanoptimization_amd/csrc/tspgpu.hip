@@ -865,7 +865,9 @@ constexpr int NN_TAIL = 256;
 template <int KIND, bool LDS_PTS, bool LDS_CS, bool KEY32, int KNN = 0>
 __global__ void __launch_bounds__(64) k_nn_grid(GridArgs A)
 {
-    static_assert(KNN == 0 || KEY32, "the neighbour lists hold 32-bit keys");
+    // (the list entries are 32-bit -- weight < 2^15 | sorted position -- whatever the key of the candidate scan: a weight that
+    // does not fit is simply not listed, k_knn_build)
+    static_assert(KNN != 1 || KEY32, "lists in LDS: the 32-bit-key form only");
     static_assert(KNN != 1 || LDS_PTS, "lists in LDS ride on the LDS-resident form");
     typedef typename std::conditional<KEY32, unsigned, u64>::type K;
     constexpr K NONE = (K)~(K)0;
@@ -4598,7 +4600,8 @@ static int build_grid(tspgpu_ctx *ctx, const double *xy, int n, double x0, doubl
 template <int KIND> static const void *nn_grid_fn(bool lds_pts, bool lds_cs, bool key32, int knn = 0)
 {
     if (knn == 1) return (const void *)k_nn_grid<KIND, true, true, true, 1>;
-    if (knn == 2) return lds_cs ? (const void *)k_nn_grid<KIND, false, true, true, 2> : (const void *)k_nn_grid<KIND, false, false, true, 2>;
+    if (knn == 2 && key32) return lds_cs ? (const void *)k_nn_grid<KIND, false, true, true, 2> : (const void *)k_nn_grid<KIND, false, false, true, 2>;
+    if (knn == 2) return lds_cs ? (const void *)k_nn_grid<KIND, false, true, false, 2> : (const void *)k_nn_grid<KIND, false, false, false, 2>;
     if (lds_pts && lds_cs) return key32 ? (const void *)k_nn_grid<KIND, true, true, true> : (const void *)k_nn_grid<KIND, true, true, false>;
     if (lds_pts) return (const void *)k_nn_grid<KIND, true, false, false>;
     return lds_cs ? (const void *)k_nn_grid<KIND, false, true, false> : (const void *)k_nn_grid<KIND, false, false, false>;
@@ -4634,7 +4637,10 @@ static int launch_nn(tspgpu_ctx *ctx, int slot0, const int *h_starts, int count)
         const int kind = ctx->ceil_int() ? KIND_CEIL_INT : ctx->kind;
         // ... and, where they fit beside them, the 3 nearest neighbours of every point (built once per instance)
         // (in LDS for a single tour; batches and tours whose points do not fit LDS read them from global memory)
-        const int knn = !key32 || ctx->opt_nn == 3 ? 0 : (lp && lc && lds + (size_t)n * NN_K * 4 <= ctx->lds_max) ? 1 : !lp ? 2 : 0;
+        // (weights past the 32-bit key -- pla85900 -- keep the 64-bit candidate scan but take the lists from global memory as well:
+        // a listed neighbour's weight is below 2^15 by construction)
+        const int knn = ctx->opt_nn == 3 || n > 131072 ? 0 : !key32 ? (lp ? 0 : 2)
+                      : (lp && lc && lds + (size_t)n * NN_K * 4 <= ctx->lds_max) ? 1 : !lp ? 2 : 0;
         A.knn = nullptr;
         if (knn) {
             if (!ctx->d_knn) {
