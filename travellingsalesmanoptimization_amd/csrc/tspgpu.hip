@@ -4227,7 +4227,7 @@ static int run_pstream(tspgpu_ctx *ctx, int slot, double *time_left_io, bool *de
         StreamArgs A;
         memset(&A, 0, sizeof A);
         A.S = ctx->S; A.mat = (const u16 *)ctx->d_mat; A.n = ctx->n; A.ld = ctx->ld; A.slot = slot;
-        A.P = P; A.budget = budget; A.poll_sleep = ctx->opt_lp_poll_sleep; A.prefetch = 0; A.ablate = ctx->opt_ablate;
+        A.P = P; A.budget = budget; A.poll_sleep = ctx->opt_lp_poll_sleep; A.ablate = ctx->opt_ablate;
         A.slots = ctx->d_lp_slots; A.ctl = d_ctl; A.hist = ctx->hist;
         A.hello_ticks = ctx->opt_lp_hello;
         if (ctx->opt_lp_fail_at > 0 && !first) { ctx->opt_lp_fail_at--; A.hello_ticks = -5000; }
