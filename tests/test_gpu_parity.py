@@ -2034,7 +2034,7 @@ def _fuzz_instance(r, O, n):
 _FUZZ_TALLY = {"ran": 0, "refused": 0, "sweeps": 0}
 
 
-@pytest.mark.parametrize("seed", range(80))
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("TSP_FUZZ_SEEDS", "80"))))
 def test_random_configurations_against_the_oracle(eng, T, O, seed):
     """differential fuzz: a random instance (uniform / lattice / clustered points in one of the three weight kinds, or a
     caller matrix), a random start tour (NN from a random node, or a random permutation), and a random point of the
